@@ -1,0 +1,158 @@
+/*
+ * rt_abi.h — C ABI of librt_amd.so: the MI355X (gfx950) replacement for the GPU hot path of
+ * IvoteSligte/raytracing_engine (per-pixel ray/scene intersection + shading).
+ *
+ * The reference has no FFI/plugin API for this path: its host (src/main.rs) reaches the GLSL
+ * kernels through vulkano descriptor sets and push constants.  The drop-in boundary is therefore
+ * that binding contract, restated as plain C:
+ *
+ *   reference interface (file:line in the reference repo)          replaced by
+ *   -------------------------------------------------------------  ---------------------------
+ *   Vulkan instance/device/queue selection  src/main.rs:418-460    rt_create / rt_destroy
+ *   spec-const RENDER_DIST  src/main.rs:521,636; compute.glsl:32;
+ *     GLSL consts fragment.glsl:35-37                              rt_set_config
+ *   set0/binding1 MutableData UBO upload  src/main.rs:593-605      rt_set_scene
+ *   ConstantBuffer{view,ratio} + image pyramid allocation
+ *     src/main.rs:203-266, 608-615, 639-648, resize :813-861       rt_resize / rt_level_info
+ *   get_command_buffer: per-level push constants + dispatch,
+ *     then the full-screen draw  src/main.rs:268-341;
+ *     submit + fence  src/main.rs:909-927                          rt_render / rt_render_spp /
+ *                                                                  rt_render_device
+ *   swapchain *_UNORM colour attachment  src/main.rs:471-486       rt_read_rgba8
+ *   (none: the reference cannot read a pyramid level back)         rt_read_level  [test hook]
+ *   FPS println  src/main.rs:719,730                               rt_get_stats
+ *
+ * Conventions: every function returns RT_OK (0) or a negative rt_status and never throws or
+ * aborts across the boundary; the caller owns every host/device pointer it passes; the context
+ * owns all device memory it allocates; one context is bound to one GPU and is single-threaded
+ * (like the reference's single queue, src/main.rs:460); distinct contexts are independent (one
+ * per GPU / per process).  There is NO CPU fallback: rt_create fails with RT_ERR_NO_DEVICE when
+ * no gfx950 device is usable.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument (NULL, size mismatch, out-of-range count) */
+    RT_ERR_NO_DEVICE = -2, /* no usable HIP device / ordinal out of range */
+    RT_ERR_HIP = -3,       /* a HIP runtime call failed; see rt_last_error */
+    RT_ERR_STATE = -4,     /* call order violated (e.g. render before set_scene/resize) */
+    RT_ERR_OOM = -5        /* host or device allocation failed */
+} rt_status;
+
+#define RT_MAX_MATERIALS 8u /* shaders/utilities.glsl:2 */
+#define RT_MAX_OBJECTS 8u   /* shaders/utilities.glsl:3 */
+#define RT_MAX_LIGHTS 8u    /* shaders/utilities.glsl:4 */
+#define RT_MAX_LEVELS 9u    /* shaders/compute.glsl:14-15; src/main.rs:359 */
+#define RT_TILE 64u         /* multi-GPU framebuffer tile edge in full-resolution pixels */
+
+/* std140 images of the reference's shader structs, byte-identical to what
+ * vulkano_shaders::shader! generates (src/main.rs:47-66; fields at :524-591), so the
+ * reference's own `shaders::ty::MutableData` can be passed by pointer. */
+typedef struct rt_material { float color[3]; float diffuse; float specular; float shine; float ambient; uint32_t _pad; } rt_material; /* 32 B, utilities.glsl:8-14 */
+typedef struct rt_object { float pos[3]; float size; } rt_object;                                                            /* 16 B, utilities.glsl:16-19 */
+typedef struct rt_light { float pos[3]; uint32_t _pad0; float color[3]; uint32_t _pad1; } rt_light;                          /* 32 B, utilities.glsl:21-24 */
+typedef struct rt_mutable_data { /* compute.glsl:17-24 == fragment.glsl:17-24; 656 B */
+    uint32_t matCount, objCount, lightCount, _pad;
+    rt_material mats[RT_MAX_MATERIALS];
+    rt_object objs[RT_MAX_OBJECTS];
+    rt_light lights[RT_MAX_LIGHTS];
+} rt_mutable_data;
+
+/* constants the reference bakes in at pipeline-creation / shader-compile time */
+typedef struct rt_config {
+    float render_dist;    /* RENDER_DIST = 1000   src/main.rs:362 */
+    float cam_fall_off;   /* CAM_FALL_OFF = 0.01  fragment.glsl:35 */
+    float light_fall_off; /* LIGHT_FALL_OFF = 0.01 fragment.glsl:36 */
+    float ray_radius;     /* RAY_RADIUS = 0.01    fragment.glsl:37 */
+    uint32_t max_steps;   /* cap on either march loop so every wave terminates (default 1<<20; 0 = none) */
+    uint32_t profile_stages; /* 1: bracket every kernel with HIP events (rt_get_stats.stage_ms) */
+} rt_config;
+
+typedef struct rt_stats {
+    uint32_t width, height, level_count, spp;
+    uint64_t frames;           /* rt_render* calls since rt_resize */
+    uint64_t primary_rays;     /* last call: width*height*spp (owned tiles only) */
+    uint64_t shadow_rays;      /* last call: lightCount per hit pixel per sample */
+    uint64_t hit_pixels;       /* last call */
+    uint64_t cone_threads;     /* last call: compute-stage invocations over all levels */
+    float    ms_total;         /* last call: HIP-event time around the whole stage loop */
+    float    ms_cone;          /* last call: sum over level kernels (profile_stages=1 only) */
+    float    ms_shade;         /* last call: shade kernel(s) (profile_stages=1 only) */
+    float    ms_level[RT_MAX_LEVELS]; /* last call, last sample (profile_stages=1 only) */
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+int rt_abi_version(void);
+int rt_device_count(int* count);
+
+/* device_ordinal >= 0: HIP device index.  No CPU backend exists. */
+int rt_create(rt_ctx** out, int device_ordinal);
+void rt_destroy(rt_ctx* ctx);
+/* message of the last failure on ctx (ctx == NULL: last rt_create failure of this thread) */
+const char* rt_last_error(const rt_ctx* ctx);
+
+int rt_default_config(rt_config* cfg);
+int rt_set_config(rt_ctx* ctx, const rt_config* cfg);
+/* default scene of src/main.rs:524-591 */
+int rt_default_scene(rt_mutable_data* scene);
+/* bytes must equal sizeof(rt_mutable_data) == 656 */
+int rt_set_scene(rt_ctx* ctx, const void* mutable_data, size_t bytes);
+
+/* (re)allocate the depth pyramid for a width x height view; ratio == NULL selects
+ * {FOV, FOV*height/width} with FOV = 1 (src/main.rs:364,610) */
+int rt_resize(rt_ctx* ctx, uint32_t width, uint32_t height, const float ratio[2]);
+/* level count (src/main.rs:639, floor form, capped at 9) and dims[level] = {w,h} (src/main.rs:209-213) */
+int rt_level_info(const rt_ctx* ctx, uint32_t* count, uint32_t dims[RT_MAX_LEVELS][2]);
+
+/* Framebuffer partition for multi-GPU rendering: RT_TILE x RT_TILE tiles, tile t (row-major)
+ * belongs to rank t % n_ranks.  Default rank 0 of 1 = whole frame. */
+int rt_set_partition(rt_ctx* ctx, uint32_t rank, uint32_t n_ranks);
+/* tiles_x, tiles_y of the current view and the number of tiles owned by this rank */
+int rt_tile_info(const rt_ctx* ctx, uint32_t* tiles_x, uint32_t* tiles_y, uint32_t* owned);
+
+/* Use an external HIP stream (hipStream_t as void*) for all launches; NULL = context's own. */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+
+/* One frame at the reference's single pixel-centre sample.  rot = quaternion [x,y,z,w]
+ * (push_constants.rot, src/main.rs:772), pos = camera position (:773).
+ * rgb_out: host, width*height*3 f32, row-major, row 0 = gl_FragCoord.y 0.5, may be NULL;
+ * depth_out: host, the last pyramid level (level dims, see rt_level_info), may be NULL.
+ * Synchronous: results are complete on return. */
+int rt_render(rt_ctx* ctx, const float rot[4], const float pos[3], float* rgb_out, float* depth_out);
+/* spp = n*n stratified sub-pixel centres (n = 1,2,3,..), each sample one full frame, averaged
+ * in sample order; spp = 1 is rt_render. */
+int rt_render_spp(rt_ctx* ctx, const float rot[4], const float pos[3], uint32_t spp, float* rgb_out);
+/* Asynchronous device-side variant: rgb_dev is a device pointer receiving either the full frame
+ * (tile_major = 0: width*height*3 f32) or only this rank's tiles packed tile-major
+ * (tile_major = 1: owned * RT_TILE*RT_TILE*3 f32, tile k = global tile rank + k*n_ranks).
+ * Work is enqueued on the context's stream; no host synchronisation. */
+int rt_render_device(rt_ctx* ctx, const float rot[4], const float pos[3], uint32_t spp, void* rgb_dev, int tile_major);
+/* Scatter gathered tile-major buffers (n_ranks * tiles_per_rank tiles, rank-major) into a full
+ * frame on the device: the de-tile step after an RCCL gather. */
+int rt_detile_device(rt_ctx* ctx, const void* tiles_dev, uint32_t n_ranks, uint32_t tiles_per_rank, void* rgb_dev);
+int rt_synchronize(rt_ctx* ctx);
+
+/* Test hook: copy pyramid level `level` of the last frame to host. */
+int rt_read_level(rt_ctx* ctx, uint32_t level, float* out, uint32_t* w, uint32_t* h);
+/* Last frame as a *_UNORM swapchain would hold it (src/main.rs:471-486): linear, clamped,
+ * round-to-nearest, alpha = 255 (never written by fragment.glsl:138,159). width*height*4 bytes. */
+int rt_read_rgba8(rt_ctx* ctx, uint8_t* rgba_out);
+
+int rt_get_stats(const rt_ctx* ctx, rt_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,110 @@
+"""ctypes binding of librt_amd.so (include/rt_abi.h).
+
+The library is the product: hand-written HIP kernels for gfx950 behind a C ABI.  There is no
+Python/CPU fallback — a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+RT_OK = 0
+RT_MAX_LEVELS = 9
+RT_TILE = 64
+STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_HIP", -4: "RT_ERR_STATE",
+                -5: "RT_ERR_OOM"}
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class Material(C.Structure):  # shaders/utilities.glsl:8-14, std140, 32 B
+    _fields_ = [("color", C.c_float * 3), ("diffuse", C.c_float), ("specular", C.c_float), ("shine", C.c_float),
+                ("ambient", C.c_float), ("_pad", C.c_uint32)]
+
+
+class Object(C.Structure):  # shaders/utilities.glsl:16-19, 16 B
+    _fields_ = [("pos", C.c_float * 3), ("size", C.c_float)]
+
+
+class Light(C.Structure):  # shaders/utilities.glsl:21-24, std140, 32 B
+    _fields_ = [("pos", C.c_float * 3), ("_pad0", C.c_uint32), ("color", C.c_float * 3), ("_pad1", C.c_uint32)]
+
+
+class MutableData(C.Structure):  # shaders/compute.glsl:17-24, 656 B
+    _fields_ = [("matCount", C.c_uint32), ("objCount", C.c_uint32), ("lightCount", C.c_uint32), ("_pad", C.c_uint32),
+                ("mats", Material * 8), ("objs", Object * 8), ("lights", Light * 8)]
+
+
+class Config(C.Structure):
+    _fields_ = [("render_dist", C.c_float), ("cam_fall_off", C.c_float), ("light_fall_off", C.c_float),
+                ("ray_radius", C.c_float), ("max_steps", C.c_uint32), ("profile_stages", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("level_count", C.c_uint32), ("spp", C.c_uint32),
+                ("frames", C.c_uint64), ("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("hit_pixels", C.c_uint64), ("cone_threads", C.c_uint64), ("ms_total", C.c_float),
+                ("ms_cone", C.c_float), ("ms_shade", C.c_float), ("ms_level", C.c_float * RT_MAX_LEVELS)]
+
+    def as_dict(self):
+        d = {}
+        for n, _ in self._fields_:
+            v = getattr(self, n)
+            d[n] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+assert C.sizeof(MutableData) == 656 and C.sizeof(Material) == 32 and C.sizeof(Object) == 16 and C.sizeof(Light) == 32
+
+# every symbol include/rt_abi.h declares: name -> (restype, argtypes)
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+_u32p = C.POINTER(C.c_uint32)
+PROTOTYPES = {
+    "rt_abi_version": (C.c_int, []),
+    "rt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rt_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "rt_destroy": (None, [_vp]),
+    "rt_last_error": (C.c_char_p, [_vp]),
+    "rt_default_config": (C.c_int, [C.POINTER(Config)]),
+    "rt_set_config": (C.c_int, [_vp, C.POINTER(Config)]),
+    "rt_default_scene": (C.c_int, [C.POINTER(MutableData)]),
+    "rt_set_scene": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "rt_resize": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _fp]),
+    "rt_level_info": (C.c_int, [_vp, _u32p, C.POINTER((C.c_uint32 * 2) * RT_MAX_LEVELS)]),
+    "rt_set_partition": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "rt_tile_info": (C.c_int, [_vp, _u32p, _u32p, _u32p]),
+    "rt_set_stream": (C.c_int, [_vp, _vp]),
+    "rt_render": (C.c_int, [_vp, _fp, _fp, _fp, _fp]),
+    "rt_render_spp": (C.c_int, [_vp, _fp, _fp, C.c_uint32, _fp]),
+    "rt_render_device": (C.c_int, [_vp, _fp, _fp, C.c_uint32, _vp, C.c_int]),
+    "rt_detile_device": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
+    "rt_synchronize": (C.c_int, [_vp]),
+    "rt_read_level": (C.c_int, [_vp, C.c_uint32, _fp, _u32p, _u32p]),
+    "rt_read_rgba8": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
+    "rt_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librt_amd.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C raytracing_engine_amd/csrc). raytracing_engine_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

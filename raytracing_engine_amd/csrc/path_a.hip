@@ -1,0 +1,323 @@
+// path_a.hip — the reference's hot path as gfx950 kernels: hierarchical sphere-SDF cone marching
+// (one launch per pyramid level) and the shading pass with soft-shadow marching.
+//
+// Replaces (file:line in the reference repo):
+//   shaders/compute.glsl:70-87 (main) + :34-68 (traceCone)      -> cone_level_kernel
+//   shaders/fragment.glsl:127-187 (main) + :89-121 (shadowRay)  -> shade_kernel
+//   shaders/utilities.glsl:26-29, 36-38                          -> rt_device_math.h, sphere_sdf
+//
+// Mapping to CDNA4: the reference's 8x8 workgroup (compute.glsl:5) is exactly one wave64, so one
+// wave owns one 8x8 pixel tile (compact footprint = similar march trip counts = less divergence);
+// a workgroup is 4 such waves.  The scene (<= 8 spheres) travels in the kernarg segment and lives
+// in SGPRs; per-lane state is the 8 lazily refreshed distance bounds (VGPRs, fully unrolled, so
+// no scratch).  These kernels are VALU/sqrt-bound (about 8 B of HBM traffic per thread); see
+// DESIGN.md §5.
+#include "rt_device_math.h"
+#include "rt_internal.h"
+
+namespace rt {
+using namespace rtk;
+
+// shaders/utilities.glsl:36-38   distance(p, s.pos) - s.size
+__device__ __forceinline__ float sphere_sdf(v3 p, float4 s) { return length(p - mk(s.x, s.y, s.z)) - s.w; }
+
+// Does this rank own the RT_TILE^2 tile containing full-res pixel (x0, y0)?  Off-screen -> false.
+__device__ __forceinline__ bool owns_pixel_tile(const Partition& part, uint32_t x0, uint32_t y0, uint32_t width,
+                                                uint32_t height) {
+    if (x0 >= width || y0 >= height) return false;
+    const uint32_t t = (y0 / RT_TILE) * part.tiles_x + (x0 / RT_TILE);
+    return t % part.n_ranks == part.rank;
+}
+
+// ---- shaders/compute.glsl:34-68 ---------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ float trace_cone(const SphereSet& S, v3 origin, v3 step, float threshold, float render_dist,
+                                            uint32_t max_steps) {
+    float distances[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) distances[i] = sphere_sdf(origin, S.s[i]);  // :37-39
+
+    float len = 0.0f, last = 0.0f;
+    uint32_t it = 0;
+    while (len < render_dist) {  // :44
+        if (max_steps && it++ >= max_steps) break;
+        const v3 position = fma3(step, len, origin);    // :45
+        float dist = render_dist;                       // :49
+        const float radius = (len + 1.0f) * threshold;  // :50
+#pragma unroll
+        for (int i = 0; i < N; i++) {  // :51-57
+            distances[i] -= last;
+            if (distances[i] <= radius) distances[i] = sphere_sdf(position, S.s[i]);
+            dist = fmin_(dist, distances[i]);
+        }
+        last = fmax_(dist, 0.0f);  // :59
+        len += last;               // :60
+        if (dist <= radius) {      // :62-65
+            len -= radius;
+            break;
+        }
+    }
+    return len;
+}
+
+// ---- shaders/compute.glsl:70-87 ---------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void cone_level_kernel(const SphereSet S, const ConeLevelParams p,
+                                                         const float* __restrict__ parent, float* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tiles_w = p.w >> 3;
+    const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);  // one 8x8 tile per wave
+    if (t >= tiles_w * (p.h >> 3)) return;                    // wave-uniform
+    const uint32_t ty = t / tiles_w, tx = t - ty * tiles_w;
+    if (p.partitioned && (8u << p.shift) <= RT_TILE) {
+        // this level tile lies inside one framebuffer tile: trace it only on the owning rank
+        if (!owns_pixel_tile(p.part, (tx * 8u) << p.shift, (ty * 8u) << p.shift, p.width, p.height)) return;
+    }
+    const uint32_t gx = tx * 8u + (lane & 7u), gy = ty * 8u + (lane >> 3);
+
+    // :71-72  (gid*2 + 1) * imageSize - 1, then * ratio   (jitter = 0 for the reference's sample)
+    float nx = __builtin_fmaf((float)(gx * 2u + 1u), p.image_size[0], -1.0f) + p.cam.jitter[0];
+    float ny = __builtin_fmaf((float)(gy * 2u + 1u), p.image_size[1], -1.0f) + p.cam.jitter[1];
+    nx *= p.cam.ratio[0];
+    ny *= p.cam.ratio[1];
+    const float threshold = (1.4142135f * 8.0f) * p.image_size[0];  // :75
+    const v3 step = normalize(rotate_q(p.cam.rot[0], p.cam.rot[1], p.cam.rot[2], p.cam.rot[3], mk(nx, 1.0f, ny)));  // :77
+
+    float len = 1.0f;                                                                   // :79
+    if (p.level > 0) len = parent[(size_t)(gy >> 1) * p.parent_w + (gx >> 1)];           // :80-82
+    const v3 pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+    len += trace_cone<N>(S, fma3(step, len, pos), step, threshold, p.render_dist, p.max_steps);  // :84
+    out[(size_t)gy * p.w + gx] = fmax_(len, 0.0f);                                               // :86
+}
+
+// ---- shaders/fragment.glsl:89-121 -------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ float shadow_ray(const float4 (&sphere)[RT_MAX_OBJECTS], v3 origin, v3 step, float end,
+                                            float ray_radius, uint32_t max_steps) {
+    float distances[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) distances[i] = sphere_sdf(origin, sphere[i]);  // :92-94
+
+    float last = 0.0f, nearest = 1.0f;  // :96-97
+    uint32_t it = 0;
+    for (float len = 0.0f; len < end; len += last + ray_radius) {  // :99
+        if (max_steps && it++ >= max_steps) break;
+        const v3 position = fma3(step, len, origin);  // :100
+        float dist = end;                             // :104
+#pragma unroll
+        for (int i = 0; i < N; i++) {  // :105-111
+            distances[i] -= last;
+            if (distances[i] <= nearest) distances[i] = sphere_sdf(position, sphere[i]);
+            dist = fmin_(dist, distances[i]);
+        }
+        if (dist <= ray_radius) return 0.0f;  // :113-115
+        last = fmax_(dist, 0.0f);             // :117
+        nearest = fmin_(nearest, dist);       // :118
+    }
+    return nearest;  // :120
+}
+
+// ---- shaders/fragment.glsl:127-187 ------------------------------------------------------------
+// Grid: 16 workgroups per owned framebuffer tile; every wave shades one 8x8 block of the tile.
+template <int N>
+__global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const ShadeParams p, const float* __restrict__ depth,
+                                                    float* __restrict__ dst, uint64_t* __restrict__ counters) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x >> 4;                                  // owned-tile index
+    const uint32_t sub = ((blockIdx.x & 15u) << 2) + (threadIdx.x >> 6);  // 8x8 block inside the tile
+    const uint32_t tile = p.part.rank + k * p.part.n_ranks;
+    const uint32_t tile_y = tile / p.part.tiles_x, tile_x = tile - tile_y * p.part.tiles_x;
+    const uint32_t lx = ((sub & 7u) << 3) + (lane & 7u), ly = ((sub >> 3) << 3) + (lane >> 3);
+    const uint32_t px = tile_x * RT_TILE + lx, py = tile_y * RT_TILE + ly;
+    const bool inside = px < p.width && py < p.height;
+
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    bool hit = false;
+    if (inside) {
+        // :129-133  gl_FragCoord.xy * 2 / cs.view - 1.0   (gl_FragCoord = pixel + 0.5)
+        float nx = (((float)px + 0.5f) * 2.0f) / p.view[0] - 1.0f + p.cam.jitter[0];
+        float ny = (((float)py + 0.5f) * 2.0f) / p.view[1] - 1.0f + p.cam.jitter[1];
+        nx *= p.cam.ratio[0];
+        ny *= p.cam.ratio[1];
+        const v3 step = normalize(rotate_q(p.cam.rot[0], p.cam.rot[1], p.cam.rot[2], p.cam.rot[3], mk(nx, 1.0f, ny)));
+        const float total_dist = depth[(size_t)py * p.depth_w + px];  // :135
+        hit = total_dist < p.render_dist;                             // :137-140 (miss -> rgb 0)
+        if (hit) {
+            const v3 pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+            const v3 position = fma3(step, total_dist, pos);  // :142
+
+            // :144-156 nearest sphere (strict '<', first wins ties); material index = object index
+            float dist = sphere_sdf(position, S.sphere[0]);
+            float4 obj = S.sphere[0];
+            float4 mat = S.mat_color_ambient[0];
+            float shine = S.mat_shine[0];
+#pragma unroll
+            for (int i = 1; i < N; i++) {
+                const float nd = sphere_sdf(position, S.sphere[i]);
+                if (nd < dist) {
+                    dist = nd;
+                    obj = S.sphere[i];
+                    mat = S.mat_color_ambient[i];
+                    shine = S.mat_shine[i];
+                }
+            }
+
+            const float cam_dist = length(position - pos);                                                    // :162
+            const float cam_fall = fmax_(p.cam_fall_off * __builtin_fmaf(cam_dist, cam_dist, 1.0f), 1.0f);   // :163
+            const v3 normal = normalize(position - mk(obj.x, obj.y, obj.z));                                  // :166
+            const v3 cam_dir = -step;
+            const float normal_fall = fmax_(dot(normal, cam_dir), 0.0f);  // :167
+
+            for (uint32_t i = 0; i < S.light_count; i++) {  // :170-186
+                const float4 lp = S.light_pos[i], lc = S.light_color[i];
+                const v3 lpos = mk(lp.x, lp.y, lp.z);
+                const v3 light_dir = normalize(lpos - position);   // :173
+                const float light_dist = length(position - lpos);  // :174
+                const float soft =
+                    fmin_(shadow_ray<N>(S.sphere, position + light_dir, light_dir, light_dist, p.ray_radius, p.max_steps), 1.0f);  // :176
+                const float light_fall = fmax_((p.light_fall_off * light_dist) * light_dist, 1.0f);  // :178
+                const float diffuse = fmax_(dot(normal, light_dir), 0.0f);                           // :180
+                // :181, :47-50  reflect(I,N) = I - 2*dot(N,I)*N with I = -lightDir
+                const v3 inc = -light_dir;
+                const float kk = 2.0f * dot(normal, inc);
+                const v3 refl = mk(__builtin_fmaf(-kk, normal.x, inc.x), __builtin_fmaf(-kk, normal.y, inc.y),
+                                   __builtin_fmaf(-kk, normal.z, inc.z));
+                const float base = dot(refl, cam_dir);
+                // pow(x<=0, y) is undefined in GLSL; defined as 0 here
+                const float spec = base > 0.0f ? fmax_(diffuse * __builtin_powf(base, shine), 0.0f) : 0.0f;
+                const float s = fmax_(diffuse + spec, 0.0f);  // :183
+                const float dr = ((s * lc.x) / light_fall) * soft;
+                const float dg = ((s * lc.y) / light_fall) * soft;
+                const float db = ((s * lc.z) / light_fall) * soft;
+                // :185  (ambient + direct) / camDistFallOff * normalFallOff * mat.color
+                r = __builtin_fmaf(((mat.w + dr) / cam_fall) * normal_fall, mat.x, r);
+                g = __builtin_fmaf(((mat.w + dg) / cam_fall) * normal_fall, mat.y, g);
+                b = __builtin_fmaf(((mat.w + db) / cam_fall) * normal_fall, mat.z, b);
+            }
+        }
+    }
+
+    const unsigned long long hits = __ballot(hit);
+    if (lane == 0 && hits) atomicAdd((unsigned long long*)&counters[0], (unsigned long long)__popcll(hits));
+
+    if (inside) {
+        const size_t idx = p.tile_major ? ((size_t)k * (RT_TILE * RT_TILE) + (size_t)ly * RT_TILE + lx)
+                                        : ((size_t)py * p.width + px);
+        float* o = dst + idx * 3;
+        if (p.mode & 1u) {  // sample accumulation, fixed order: ((s0 + s1) + s2) + ...
+            r = o[0] + r;
+            g = o[1] + g;
+            b = o[2] + b;
+        }
+        if (p.mode & 2u) {
+            r = r / p.spp;
+            g = g / p.spp;
+            b = b / p.spp;
+        }
+        o[0] = r;
+        o[1] = g;
+        o[2] = b;
+    }
+}
+
+// Scatter rank-major, tile-major gathered buffers into a full frame (one thread per pixel).
+__global__ __launch_bounds__(256) void detile_kernel(const float* __restrict__ tiles, uint32_t n_ranks, uint32_t tiles_per_rank,
+                                                     uint32_t tiles_x, uint32_t tiles_y, uint32_t width, uint32_t height,
+                                                     float* __restrict__ rgb) {
+    const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t py = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (px >= width || py >= height) return;
+    const uint32_t tile = (py / RT_TILE) * tiles_x + (px / RT_TILE);
+    const uint32_t rank = tile % n_ranks, k = tile / n_ranks;
+    const size_t src = ((size_t)rank * tiles_per_rank + k) * (RT_TILE * RT_TILE) + (size_t)(py % RT_TILE) * RT_TILE + (px % RT_TILE);
+    const size_t dst = (size_t)py * width + px;
+    rgb[dst * 3 + 0] = tiles[src * 3 + 0];
+    rgb[dst * 3 + 1] = tiles[src * 3 + 1];
+    rgb[dst * 3 + 2] = tiles[src * 3 + 2];
+    (void)tiles_y;
+}
+
+// linear f32 -> UNORM8 (clamp, *255, round-to-nearest-even), alpha = 255
+__global__ __launch_bounds__(256) void to_rgba8_kernel(const float* __restrict__ rgb, uint32_t* __restrict__ rgba, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t packed = 0xff000000u;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float v = rgb[i * 3 + c];
+        v = v > 0.0f ? v : 0.0f;
+        v = v < 1.0f ? v : 1.0f;
+        packed |= (uint32_t)__builtin_rintf(v * 255.0f) << (8 * c);
+    }
+    rgba[i] = packed;
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+template <int N>
+static void cone_launch_n(hipStream_t st, dim3 grid, const SphereSet& S, const ConeLevelParams& p, const float* parent, float* out) {
+    hipLaunchKernelGGL(cone_level_kernel<N>, grid, dim3(256), 0, st, S, p, parent, out);
+}
+template <int N>
+static void shade_launch_n(hipStream_t st, dim3 grid, const ShadeSet& S, const ShadeParams& p, const float* depth, float* dst,
+                           uint64_t* counters) {
+    hipLaunchKernelGGL(shade_kernel<N>, grid, dim3(256), 0, st, S, p, depth, dst, counters);
+}
+
+int launch_cone_level(Ctx* c, const SphereSet& S, uint32_t n_obj, const ConeLevelParams& p, const float* parent, float* out) {
+    if (n_obj < 1 || n_obj > RT_MAX_OBJECTS) return c->fail(RT_ERR_INVALID, "objCount %u out of [1,8]", n_obj);
+    if ((p.w & 7u) || (p.h & 7u) || p.w == 0 || p.h == 0) return c->fail(RT_ERR_INVALID, "level dims %ux%u not multiples of 8", p.w, p.h);
+    if (p.level > 0 && (parent == nullptr || p.parent_w * 2u < p.w)) return c->fail(RT_ERR_INVALID, "level %u: bad parent image", p.level);
+    const uint32_t tiles = (p.w >> 3) * (p.h >> 3);
+    const dim3 grid((tiles + 3u) / 4u);
+    switch (n_obj) {
+        case 1: cone_launch_n<1>(c->stream, grid, S, p, parent, out); break;
+        case 2: cone_launch_n<2>(c->stream, grid, S, p, parent, out); break;
+        case 3: cone_launch_n<3>(c->stream, grid, S, p, parent, out); break;
+        case 4: cone_launch_n<4>(c->stream, grid, S, p, parent, out); break;
+        case 5: cone_launch_n<5>(c->stream, grid, S, p, parent, out); break;
+        case 6: cone_launch_n<6>(c->stream, grid, S, p, parent, out); break;
+        case 7: cone_launch_n<7>(c->stream, grid, S, p, parent, out); break;
+        default: cone_launch_n<8>(c->stream, grid, S, p, parent, out); break;
+    }
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_shade(Ctx* c, const ShadeSet& S, uint32_t n_obj, const ShadeParams& p, const float* depth, float* dst, uint64_t* counters) {
+    if (n_obj < 1 || n_obj > RT_MAX_OBJECTS) return c->fail(RT_ERR_INVALID, "objCount %u out of [1,8]", n_obj);
+    if (p.depth_w < p.width) return c->fail(RT_ERR_INVALID, "depth pitch %u < width %u", p.depth_w, p.width);
+    const uint32_t total = p.part.tiles_x * p.part.tiles_y;
+    if (p.part.n_ranks == 0 || p.part.rank >= p.part.n_ranks) return c->fail(RT_ERR_INVALID, "bad partition");
+    const uint32_t owned = total > p.part.rank ? (total - p.part.rank + p.part.n_ranks - 1u) / p.part.n_ranks : 0u;
+    if (owned == 0) return RT_OK;
+    const dim3 grid(owned * 16u);
+    switch (n_obj) {
+        case 1: shade_launch_n<1>(c->stream, grid, S, p, depth, dst, counters); break;
+        case 2: shade_launch_n<2>(c->stream, grid, S, p, depth, dst, counters); break;
+        case 3: shade_launch_n<3>(c->stream, grid, S, p, depth, dst, counters); break;
+        case 4: shade_launch_n<4>(c->stream, grid, S, p, depth, dst, counters); break;
+        case 5: shade_launch_n<5>(c->stream, grid, S, p, depth, dst, counters); break;
+        case 6: shade_launch_n<6>(c->stream, grid, S, p, depth, dst, counters); break;
+        case 7: shade_launch_n<7>(c->stream, grid, S, p, depth, dst, counters); break;
+        default: shade_launch_n<8>(c->stream, grid, S, p, depth, dst, counters); break;
+    }
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_detile(Ctx* c, const float* tiles, uint32_t n_ranks, uint32_t tiles_per_rank, float* rgb) {
+    const dim3 grid((c->width + 63u) / 64u, (c->height + 3u) / 4u);
+    hipLaunchKernelGGL(detile_kernel, grid, dim3(256), 0, c->stream, tiles, n_ranks, tiles_per_rank, c->part.tiles_x, c->part.tiles_y,
+                       c->width, c->height, rgb);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_to_rgba8(Ctx* c, const float* rgb, uint8_t* rgba, uint64_t n_pixels) {
+    const dim3 grid((unsigned)((n_pixels + 255u) / 256u));
+    hipLaunchKernelGGL(to_rgba8_kernel, grid, dim3(256), 0, c->stream, rgb, (uint32_t*)rgba, n_pixels);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace rt

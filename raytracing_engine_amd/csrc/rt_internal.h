@@ -1,0 +1,127 @@
+// rt_internal.h — context object and launch-parameter blocks shared by the .hip files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+
+static_assert(sizeof(rt_material) == 32, "std140 Material stride");
+static_assert(sizeof(rt_object) == 16, "std140 Object stride");
+static_assert(sizeof(rt_light) == 32, "std140 Light stride");
+static_assert(sizeof(rt_mutable_data) == 656, "std140 MutableData size");
+static_assert(offsetof(rt_mutable_data, mats) == 16 && offsetof(rt_mutable_data, objs) == 272 &&
+                  offsetof(rt_mutable_data, lights) == 400,
+              "std140 MutableData offsets");
+
+namespace rt {
+
+// Spheres of the scene, passed by value in the kernarg segment: the compiler keeps them in
+// SGPRs (s_load from kernarg), so the 8 objects cost no VGPRs and no vector memory traffic.
+struct SphereSet {
+    float4 s[RT_MAX_OBJECTS];  // xyz = centre, w = radius
+};
+
+struct ShadeSet {  // everything fragment.glsl reads from MutableData
+    float4 sphere[RT_MAX_OBJECTS];
+    float4 mat_color_ambient[RT_MAX_MATERIALS];  // rgb, ambient
+    float mat_shine[RT_MAX_MATERIALS];
+    float4 light_pos[RT_MAX_LIGHTS];
+    float4 light_color[RT_MAX_LIGHTS];
+    uint32_t light_count;
+};
+
+// Framebuffer partition (multi-GPU): RT_TILE^2 tiles, tile t belongs to rank t % n_ranks.
+struct Partition {
+    uint32_t rank, n_ranks, tiles_x, tiles_y;
+};
+
+struct Camera {
+    float rot[4];
+    float pos[3];
+    float ratio[2];
+    float jitter[2];
+};
+
+// compute.glsl push constants + ConstantBuffer for one pyramid level
+struct ConeLevelParams {
+    Camera cam;
+    float image_size[2];  // 2^(count-1-level) / view   (src/main.rs:303-305)
+    uint32_t level;       // pc.iter
+    uint32_t w, h;        // level image dims (multiples of 8)
+    uint32_t parent_w;
+    uint32_t shift;       // count-1-level: level pixel -> full-res pixel
+    uint32_t width, height;  // full-res view
+    float render_dist;
+    uint32_t max_steps;
+    Partition part;
+    uint32_t partitioned;  // 1: skip level tiles this rank does not own / that are off-screen
+};
+
+struct ShadeParams {
+    Camera cam;
+    float view[2];
+    uint32_t width, height;
+    uint32_t depth_w;  // row pitch of the last pyramid level
+    float render_dist, cam_fall_off, light_fall_off, ray_radius;
+    uint32_t max_steps;
+    Partition part;
+    uint32_t tile_major;  // 0: dst is a full frame, 1: dst holds owned tiles packed tile-major
+    uint32_t mode;        // bit0: accumulate onto dst, bit1: divide by spp after adding
+    float spp;
+};
+
+struct Ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    rt_config cfg{};
+    bool have_scene = false;
+    rt_mutable_data scene{};
+
+    uint32_t width = 0, height = 0;
+    float ratio[2] = {1.0f, 1.0f};
+    uint32_t level_count = 0;
+    uint32_t dims[RT_MAX_LEVELS][2] = {};
+    float* d_level[RT_MAX_LEVELS] = {};
+    float* d_rgb = nullptr;         // full frame, f32 x 3
+    uint64_t* d_counters = nullptr;  // [0] hit pixels
+    Partition part{0, 1, 0, 0};
+
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_stage;  // profile_stages
+    rt_stats stats{};
+    bool frame_valid = false;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define RT_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return (ctx)->fail(RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// path_a.hip
+int launch_cone_level(Ctx* c, const SphereSet& spheres, uint32_t n_obj, const ConeLevelParams& p, const float* parent,
+                      float* out);
+int launch_shade(Ctx* c, const ShadeSet& set, uint32_t n_obj, const ShadeParams& p, const float* depth, float* dst,
+                 uint64_t* counters);
+int launch_detile(Ctx* c, const float* tiles, uint32_t n_ranks, uint32_t tiles_per_rank, float* rgb);
+int launch_to_rgba8(Ctx* c, const float* rgb, uint8_t* rgba, uint64_t n_pixels);
+
+}  // namespace rt
