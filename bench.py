@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric: Mrays/s).
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one synthetic frame: every rank renders its framebuffer
+tiles (64x64, dealt round-robin) with inputs resident in HBM, the tiles are gathered to rank 0
+over RCCL and de-tiled there.  value = rays traced by all ranks / max-over-ranks wall time.
+Rank 0 prints ONE JSON line (with `roofline` for the dominant kernel and `cpu_baseline` = the CPU
+oracle timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="spheres8_1080p_4spp")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+# ---- workloads -----------------------------------------------------------------------------
+class SpheresWorkload:
+    """BASELINE.json configs[1]: the 8-sphere Cornell-style scene, 1920x1080, 4 spp, path A
+    (reference-faithful cone marcher + shading; 4 spp = 2x2 stratified full frames, averaged)."""
+
+    name = "spheres8_1080p_4spp"
+    width, height, spp = 1920, 1080, 4
+    dtype = "f32"
+
+    def __init__(self, R, renderer):
+        self.R, self.r = R, renderer
+        self.scene = R.cornell_scene()
+        self.rot = np.array([0, 0, 0, 1], np.float32)
+        self.pos = np.zeros(3, np.float32)
+        renderer.set_scene(self.scene)
+        renderer.resize(self.width, self.height)
+
+    def describe(self):
+        return {"workload": f"{self.name}: Cornell-style room of 8 sphere SDFs + 1 soft-shadowed point light, "
+                            f"{self.width}x{self.height}, {self.spp} spp (2x2 stratified), path A cone-march + shade",
+                "width": self.width, "height": self.height, "spp": self.spp, "tile": 64}
+
+    def step(self, out_ptr, tile_major):
+        self.r.render_device(self.rot, self.pos, self.spp, out_ptr, tile_major)
+
+    def rays_per_step(self):
+        """Rays of THIS rank for one step (after at least one synchronous render)."""
+        self.r.render(self.rot, self.pos, spp=self.spp)
+        st = self.r.stats()
+        return st["primary_rays"] + st["shadow_rays"]
+
+    def roofline(self):
+        """HIP-event duration of each kernel (profile_stages) -> dominant kernel vs the HBM roofline.
+        Algorithmic bytes: cone level = 8 B/thread (4 B parent read + 4 B store),
+        shade = 16 B/pixel (4 B depth read + 12 B rgb store)."""
+        cfg = self.r.default_config()
+        cfg.profile_stages = 1
+        self.r.set_config(cfg)
+        reps, lv, sh = 10, None, 0.0
+        for _ in range(reps):
+            self.r.render(self.rot, self.pos, spp=self.spp)
+            st = self.r.stats()
+            lv = np.array(st["ms_level"]) if lv is None else lv + np.array(st["ms_level"])
+            sh += st["ms_shade"]
+        cfg.profile_stages = 0
+        self.r.set_config(cfg)
+        lv, sh = lv / reps, sh / reps
+        dims = self.r.level_info()
+        last = len(dims) - 1
+        kernels = {f"cone_level_kernel(level {last})": (lv[last], dims[last][0] * dims[last][1] * 8.0),
+                   "shade_kernel": (sh, self.width * self.height * 16.0)}
+        name = max(kernels, key=lambda k: kernels[k][0])
+        ms, nbytes = kernels[name]
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_kernel_ms": round(float(ms), 4),
+                "algorithmic_bytes_per_launch": nbytes,
+                "note": "path A is VALU/sqrt-bound by construction (about 16 B of HBM traffic per pixel against "
+                        "thousands of flops); the HBM fraction is reported as the contract asks, not as the limiter",
+                "all_kernels_ms": {k: round(float(v[0]), 4) for k, v in kernels.items()}}
+
+    def cpu_baseline(self):
+        import oracle as O
+
+        threads = os.cpu_count() or 1
+        sc = O.scene_from_bytes(bytes(self.scene))
+        n = 2
+        O.render_a(sc, 64, 64)  # warm the OpenMP pool
+        t0 = time.perf_counter()
+        rays = 0
+        for s in range(self.spp):
+            i, j = s % n, s // n
+            jit = (((np.float32(2 * i + 1) / np.float32(n)) - np.float32(1)) / np.float32(self.width),
+                   ((np.float32(2 * j + 1) / np.float32(n)) - np.float32(1)) / np.float32(self.height))
+            ct = O.render_a(sc, self.width, self.height, rot=self.rot, pos=self.pos, jitter=jit, want_levels=False,
+                            threads=threads)["counters"]
+            rays += self.width * self.height + ct["shadow_rays"]
+        dt = time.perf_counter() - t0
+        return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                "sample": f"the full workload once ({self.spp} spp x {self.width}x{self.height}) with oracle A "
+                          f"(OpenMP, {threads} threads), {dt:.2f} s"}
+
+
+WORKLOADS = {SpheresWorkload.name: SpheresWorkload}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+
+    import raytracing_engine_amd as R
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    r = R.Renderer(local_rank)  # raises when librt_amd.so / the GPU is missing: no fallback
+    wl = WORKLOADS[args.workload](R, r)
+    r.set_partition(rank, world)
+    tx, ty, owned = r.tile_info()
+    tiles_per_rank = -(-(tx * ty) // world)
+    T = 64
+    frame = torch.empty((wl.height, wl.width, 3), dtype=torch.float32, device=dev)
+    if world > 1:
+        mine = torch.zeros((tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev)
+        gathered = torch.empty((world, tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+        r.set_stream(torch.cuda.current_stream().cuda_stream)  # render, gather and de-tile in stream order
+
+    def step():
+        if world == 1:
+            wl.step(frame.data_ptr(), False)
+        else:
+            wl.step(mine.data_ptr(), True)
+            dist.gather(mine, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                r.detile_device(gathered.data_ptr(), world, tiles_per_rank, frame.data_ptr())
+
+    def fence():
+        r.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+
+    rays = wl.rays_per_step()
+    tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt, rays = float(tmax[0]), float(tot[1])
+    else:
+        dt, rays = float(tot[0]), float(tot[1])
+
+    if rank == 0:
+        out = {"metric": "Mrays/s", "value": round(rays * args.steps / dt / 1e6, 3), "unit": "Mrays/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
+               "config": dict(wl.describe(), parallelism=f"tile-split x{world}" if world > 1 else "single GPU",
+                              rays_per_step=int(rays))}
+        if world > 1:
+            r.set_stream(None)
+        r.set_partition(0, 1)
+        if world == 1:
+            out["roofline"] = wl.roofline()
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = wl.cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

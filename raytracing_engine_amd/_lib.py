@@ -93,6 +93,24 @@ PROTOTYPES = {
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).  Two HIP
+    runtimes in one process cannot both open the GPU ("No HIP GPUs are available"), so when torch
+    is installed its copy is loaded first and librt_amd.so's NEEDED libamdhip64.so.7 resolves to
+    it.  A process without torch (host/rt_host.cpp) uses /opt/rocm's runtime via RUNPATH."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load librt_amd.so; raises if the HIP extension has not been built (no fallback)."""
     global _lib
@@ -101,6 +119,7 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C raytracing_engine_amd/csrc). raytracing_engine_amd has no CPU fallback.")
+        _preload_shared_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
