@@ -34,6 +34,19 @@ def parse():
     return ap.parse_args()
 
 
+def host_threads():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 CPUs but grants 16 per GPU)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 # ---- workloads -----------------------------------------------------------------------------
 class SpheresWorkload:
     """BASELINE.json configs[1]: the 8-sphere Cornell-style scene, 1920x1080, 4 spp, path A
@@ -98,7 +111,7 @@ class SpheresWorkload:
     def cpu_baseline(self):
         import oracle as O
 
-        threads = os.cpu_count() or 1
+        threads = host_threads()
         sc = O.scene_from_bytes(bytes(self.scene))
         n = 2
         O.render_a(sc, 64, 64)  # warm the OpenMP pool
