@@ -152,6 +152,48 @@ int rt_read_rgba8(rt_ctx* ctx, uint8_t* rgba_out);
 
 int rt_get_stats(const rt_ctx* ctx, rt_stats* stats);
 
+/* ------------------------------------------------------------------------------------------------
+ * Path B — build-defined extension (BASELINE.json configs[2..4]): triangle meshes, a BVH and a
+ * wavefront path tracer.  NO REFERENCE COUNTERPART: the reference has only sphere SDFs, one
+ * deterministic sample and direct lighting (shaders/utilities.glsl:16-19, fragment.glsl:123-126
+ * list reflection etc. as TODO).  The camera model (rot/pos/ratio, rt_resize) and the framebuffer
+ * partition are shared with path A.  Specification: DESIGN.md §6.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct rt_pt_params {
+    uint32_t spp;      /* samples per pixel (any value >= 1) */
+    uint32_t bounces;  /* indirect bounces after the camera ray (0..15) */
+    uint32_t seed;
+    float sky[3];      /* radiance of rays that leave the scene */
+    float ray_eps;     /* origin offset along the shading normal (default 1e-3) */
+    uint32_t count_traversal; /* 1: count BVH nodes fetched / triangles tested (rt_pt_stats) */
+    uint32_t max_paths;       /* cap on paths in flight per pass (0 = default 2^25); spp is split into passes */
+} rt_pt_params;
+
+typedef struct rt_pt_stats {
+    uint32_t n_tris, n_nodes, bvh_depth, n_lights;
+    float bvh_build_ms;
+    uint32_t stack_overflow;   /* must be 0: traversal stack never exceeded */
+    uint64_t camera_rays, bounce_rays, shadow_rays; /* last render: rays handed to BVH traversal */
+    uint64_t nodes_visited, tris_tested;            /* last render, count_traversal = 1 only */
+    float ms_total;            /* last render: HIP-event time around the stage loop */
+    float ms_generate, ms_trace_closest, ms_shade, ms_trace_shadow, ms_resolve; /* profile_stages = 1 only */
+    uint32_t launches_trace_closest, launches_trace_shadow;
+} rt_pt_stats;
+
+int rt_default_pt_params(rt_pt_params* p);
+/* verts: n_tris*9 (v0,v1,v2), albedo: n_tris*3, emission: n_tris*3 (any component > 0 = light).
+ * Uploads the mesh and builds the BVH on the host (binned SAH).  Host pointers, copied. */
+int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const float* emission, uint32_t n_tris);
+/* Synchronous path-traced frame of the current view (rt_resize) into host memory. */
+int rt_render_pt(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, float* rgb_out);
+/* Asynchronous device-side variant, same output layouts as rt_render_device. */
+int rt_render_pt_device(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, void* rgb_dev, int tile_major);
+int rt_get_pt_stats(rt_ctx* ctx, rt_pt_stats* stats);
+/* Test hook: trace n caller-supplied rays (host arrays, n*3 each).  any_hit = 0: closest hit,
+ * t_out[i] = distance (inf on miss), tri_out[i] = original triangle index or -1;
+ * any_hit = 1: tri_out[i] = 1 if the open segment (o, o + 0.999*d) is occluded. */
+int rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int32_t* tri_out);
+
 #ifdef __cplusplus
 }
 #endif

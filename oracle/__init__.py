@@ -181,3 +181,115 @@ def to_unorm8(rgb):
     out = np.zeros((rgb_.shape[0], 4), np.uint8)
     lib().ora_to_unorm8(p, rgb_.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out.reshape(rgb.shape[:-1] + (4,))
+
+
+# ---- oracle B (triangles + BVH + path tracing; no reference counterpart) ---------------------
+class _Mesh(C.Structure):
+    _fields_ = [("n_tris", C.c_uint32), ("verts", C.POINTER(C.c_float)), ("albedo", C.POINTER(C.c_float)),
+                ("emission", C.POINTER(C.c_float))]
+
+
+class PtParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("bounces", C.c_uint32),
+                ("seed", C.c_uint32), ("ratio", C.c_float * 2), ("rot", C.c_float * 4), ("pos", C.c_float * 3),
+                ("sky", C.c_float * 3), ("ray_eps", C.c_float)]
+
+
+class PtCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested", "n_nodes")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+_b_ready = False
+
+
+def _libb():
+    global _b_ready
+    L = lib()
+    if not _b_ready:
+        fp = C.POINTER(C.c_float)
+        L.orb_scene_create.argtypes = [C.POINTER(_Mesh)]
+        L.orb_scene_create.restype = C.c_void_p
+        L.orb_scene_destroy.argtypes = [C.c_void_p]
+        L.orb_render.argtypes = [C.c_void_p, C.POINTER(PtParams), fp, C.POINTER(PtCounters), C.c_int, C.c_int]
+        L.orb_render.restype = C.c_int
+        L.orb_closest_hit.argtypes = [C.c_void_p, fp, fp, fp, C.c_int]
+        L.orb_closest_hit.restype = C.c_int32
+        L.orb_occluded.argtypes = [C.c_void_p, fp, fp, C.c_int]
+        L.orb_occluded.restype = C.c_int
+        L.orb_rand.argtypes = [C.c_uint32] * 5
+        L.orb_rand.restype = C.c_float
+        L.orb_cosine_dir.argtypes = [fp, C.c_float, C.c_float, fp]
+        L.orb_sincos_2pi.argtypes = [C.c_float, fp, fp]
+        _b_ready = True
+    return L
+
+
+class TriScene:
+    """Mesh + the oracle's own BVH (orb_scene)."""
+
+    def __init__(self, verts, albedo, emission):
+        self.verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 9)
+        self.albedo = np.ascontiguousarray(albedo, np.float32).reshape(-1, 3)
+        self.emission = np.ascontiguousarray(emission, np.float32).reshape(-1, 3)
+        n = self.verts.shape[0]
+        assert self.albedo.shape[0] == n and self.emission.shape[0] == n
+        fp = C.POINTER(C.c_float)
+        m = _Mesh(n, self.verts.ctypes.data_as(fp), self.albedo.ctypes.data_as(fp), self.emission.ctypes.data_as(fp))
+        self._h = _libb().orb_scene_create(C.byref(m))
+        if not self._h:
+            raise RuntimeError("orb_scene_create failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _libb().orb_scene_destroy(self._h)
+            self._h = None
+
+    def render(self, width, height, spp=1, bounces=1, seed=1, rot=(0, 0, 0, 1), pos=(0, 0, 0), ratio=None,
+               sky=(0.0, 0.0, 0.0), ray_eps=1e-3, use_bvh=True, threads=0):
+        p = PtParams()
+        p.width, p.height, p.spp, p.bounces, p.seed = width, height, spp, bounces, seed
+        if ratio is None:
+            ratio = (1.0, np.float32(1.0) * np.float32(height) / np.float32(width))
+        p.ratio[:] = [float(np.float32(x)) for x in ratio]
+        p.rot[:] = [float(np.float32(x)) for x in rot]
+        p.pos[:] = [float(np.float32(x)) for x in pos]
+        p.sky[:] = [float(np.float32(x)) for x in sky]
+        p.ray_eps = ray_eps
+        rgb = np.zeros((height, width, 3), np.float32)
+        ct = PtCounters()
+        rc = _libb().orb_render(self._h, C.byref(p), rgb.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ct), int(use_bvh), threads)
+        if rc:
+            raise RuntimeError(f"orb_render failed: {rc}")
+        return rgb, ct.as_dict()
+
+    def closest_hit(self, origin, direction, use_bvh=True):
+        o_, op = _f(origin)
+        d_, dp = _f(direction)
+        t = C.c_float()
+        tri = _libb().orb_closest_hit(self._h, op, dp, C.byref(t), int(use_bvh))
+        return int(tri), float(t.value)
+
+    def occluded(self, origin, direction, use_bvh=True):
+        o_, op = _f(origin)
+        d_, dp = _f(direction)
+        return bool(_libb().orb_occluded(self._h, op, dp, int(use_bvh)))
+
+
+def pt_rand(pixel, sample, depth, dim, seed):
+    return float(_libb().orb_rand(pixel, sample, depth, dim, seed))
+
+
+def cosine_dir(n, u1, u2):
+    n_, np_ = _f(n)
+    out = np.zeros(3, np.float32)
+    _libb().orb_cosine_dir(np_, u1, u2, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def sincos_2pi(u):
+    s, c = C.c_float(), C.c_float()
+    _libb().orb_sincos_2pi(u, C.byref(s), C.byref(c))
+    return float(s.value), float(c.value)

@@ -101,6 +101,56 @@ void ora_rotate(const float q[4], const float v[3], float out[3]);
 /* linear float -> UNORM8 as a *_UNORM swapchain stores it (src/main.rs:471-486): clamp, *255, rint */
 void ora_to_unorm8(const float* rgb, uint64_t n_pixels, uint8_t* rgba);
 
+/* =========================================================================================
+ * Oracle B — build-defined extension (BASELINE.json configs[2..4]): triangles + BVH + path
+ * tracing.  NO REFERENCE COUNTERPART (SURVEY.md §0, §8a last row): the reference has no
+ * triangles, BVH, RNG, spp or bounces, so parity for this path is "HIP kernels vs this
+ * oracle" only — "parity unpinned by the reference".  The specification both sides implement
+ * is DESIGN.md §6.
+ * ========================================================================================= */
+typedef struct {
+    uint32_t n_tris;
+    const float* verts;    /* n_tris * 9: v0, v1, v2 */
+    const float* albedo;   /* n_tris * 3 */
+    const float* emission; /* n_tris * 3; a triangle with any component > 0 is a light */
+} orb_mesh;
+
+typedef struct {
+    uint32_t width, height;
+    uint32_t spp;      /* samples per pixel */
+    uint32_t bounces;  /* indirect bounces after the camera ray */
+    uint32_t seed;
+    float ratio[2];
+    float rot[4];
+    float pos[3];
+    float sky[3];      /* radiance of rays that leave the scene */
+    float ray_eps;     /* origin offset along the shading normal */
+} orb_params;
+
+typedef struct {
+    uint64_t camera_rays, bounce_rays, shadow_rays; /* rays handed to BVH traversal */
+    uint64_t nodes_visited;  /* BVH2 child-pair nodes fetched, all rays */
+    uint64_t tris_tested;    /* ray/triangle tests, all rays */
+    uint64_t n_nodes;        /* size of the oracle's own BVH */
+} orb_counters;
+
+typedef struct orb_scene orb_scene; /* mesh + the oracle's own BVH */
+orb_scene* orb_scene_create(const orb_mesh* mesh);
+void orb_scene_destroy(orb_scene* s);
+
+/* rgb: width*height*3, row 0 = py 0.  use_bvh = 0: brute force over all triangles (small
+ * scenes only; independent cross-check of the BVH path).  threads <= 0: all. */
+int orb_render(const orb_scene* s, const orb_params* p, float* rgb, orb_counters* ct, int use_bvh, int threads);
+
+/* single-ray hooks for the known-answer tests: closest hit (returns triangle index or -1,
+ * *t_out = distance) and occlusion of the open segment (origin, origin + dir) */
+int32_t orb_closest_hit(const orb_scene* s, const float origin[3], const float dir[3], float* t_out, int use_bvh);
+int orb_occluded(const orb_scene* s, const float origin[3], const float dir[3], int use_bvh);
+/* the spec's RNG and direction sampler, exposed for KATs */
+float orb_rand(uint32_t pixel, uint32_t sample, uint32_t depth, uint32_t dim, uint32_t seed);
+void orb_cosine_dir(const float n[3], float u1, float u2, float out[3]);
+void orb_sincos_2pi(float u, float* s, float* c);
+
 #ifdef __cplusplus
 }
 #endif

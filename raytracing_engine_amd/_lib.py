@@ -59,6 +59,23 @@ class Stats(C.Structure):
         return d
 
 
+class PtParams(C.Structure):  # rt_pt_params
+    _fields_ = [("spp", C.c_uint32), ("bounces", C.c_uint32), ("seed", C.c_uint32), ("sky", C.c_float * 3),
+                ("ray_eps", C.c_float), ("count_traversal", C.c_uint32), ("max_paths", C.c_uint32)]
+
+
+class PtStats(C.Structure):  # rt_pt_stats
+    _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("n_lights", C.c_uint32),
+                ("bvh_build_ms", C.c_float), ("stack_overflow", C.c_uint32), ("camera_rays", C.c_uint64),
+                ("bounce_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64),
+                ("tris_tested", C.c_uint64), ("ms_total", C.c_float), ("ms_generate", C.c_float),
+                ("ms_trace_closest", C.c_float), ("ms_shade", C.c_float), ("ms_trace_shadow", C.c_float),
+                ("ms_resolve", C.c_float), ("launches_trace_closest", C.c_uint32), ("launches_trace_shadow", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 assert C.sizeof(MutableData) == 656 and C.sizeof(Material) == 32 and C.sizeof(Object) == 16 and C.sizeof(Light) == 32
 
 # every symbol include/rt_abi.h declares: name -> (restype, argtypes)
@@ -88,6 +105,12 @@ PROTOTYPES = {
     "rt_read_level": (C.c_int, [_vp, C.c_uint32, _fp, _u32p, _u32p]),
     "rt_read_rgba8": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
     "rt_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "rt_default_pt_params": (C.c_int, [C.POINTER(PtParams)]),
+    "rt_set_mesh": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32]),
+    "rt_render_pt": (C.c_int, [_vp, _fp, _fp, C.POINTER(PtParams), _fp]),
+    "rt_render_pt_device": (C.c_int, [_vp, _fp, _fp, C.POINTER(PtParams), _vp, C.c_int]),
+    "rt_get_pt_stats": (C.c_int, [_vp, C.POINTER(PtStats)]),
+    "rt_trace_rays": (C.c_int, [_vp, _fp, _fp, C.c_uint32, C.c_int, _fp, C.POINTER(C.c_int32)]),
 }
 
 _lib = None

@@ -290,6 +290,8 @@ int rt_create(rt_ctx** out, int device_ordinal) {
         return RT_ERR_HIP;
     }
     c->stream = c->own_stream;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) c->n_cus = cus;
     *out = reinterpret_cast<rt_ctx*>(c);
     return RT_OK;
 }
@@ -300,6 +302,7 @@ void rt_destroy(rt_ctx* ctx) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_frame(c);
+    rt::pt_free(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     for (auto ev : c->ev_stage) (void)hipEventDestroy(ev);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);

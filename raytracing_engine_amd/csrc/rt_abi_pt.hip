@@ -1,0 +1,398 @@
+// rt_abi_pt.hip — C-ABI entry points of path B (triangle mesh + BVH + wavefront path tracer) and
+// the host-side stage schedule.  No reference counterpart (include/rt_abi.h, "Path B").
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "bvh_build.h"
+#include "rt_internal.h"
+
+using rt::Ctx;
+using rt::PtData;
+
+namespace {
+
+constexpr uint64_t kMaxPathsInFlight = 1ull << 25;  // 33.5 M paths = 4.3 GB of wavefront state
+constexpr uint32_t kMaxBounces = 15;
+
+int bind(Ctx* c) {
+    RT_HIP(c, hipSetDevice(c->device));
+    return RT_OK;
+}
+
+template <class T>
+void dfree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_wavefront(PtData& pt) {
+    dfree(pt.st.ray_o);
+    dfree(pt.st.ray_d);
+    dfree(pt.st.thr);
+    dfree(pt.st.rad);
+    dfree(pt.st.hit);
+    dfree(pt.st.sh_o);
+    dfree(pt.st.sh_d);
+    dfree(pt.st.sh_c);
+    dfree(pt.d_queue[0]);
+    dfree(pt.d_queue[1]);
+    dfree(pt.d_acc);
+    pt.cap_paths = 0;
+    pt.cap_slots = 0;
+}
+
+void free_mesh(PtData& pt) {
+    dfree(pt.d_nodes);
+    dfree(pt.d_tris);
+    dfree(pt.d_albedo);
+    dfree(pt.d_emission);
+    dfree(pt.d_lights);
+    pt.n_tris = pt.n_nodes = pt.n_lights = 0;
+}
+
+template <class T>
+bool dalloc(T*& p, size_t count) {
+    return hipMalloc((void**)&p, count * sizeof(T)) == hipSuccess;
+}
+
+int ensure_wavefront(Ctx* c, uint64_t n_paths, uint64_t n_slots) {
+    PtData& pt = c->pt;
+    if (!pt.d_ctr) {
+        if (!dalloc(pt.d_ctr, (size_t)rt::PT_CTR_STRIDE * (kMaxBounces + 3)) || !dalloc(pt.d_stats, 4)) return c->fail(RT_ERR_OOM, "path-tracer counters");
+    }
+    if (n_paths > pt.cap_paths || n_slots > pt.cap_slots) {
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        free_wavefront(pt);
+        const size_t n = (size_t)n_paths;
+        const bool ok = dalloc(pt.st.ray_o, n) && dalloc(pt.st.ray_d, n) && dalloc(pt.st.thr, n) && dalloc(pt.st.rad, n) && dalloc(pt.st.hit, n) &&
+                        dalloc(pt.st.sh_o, n) && dalloc(pt.st.sh_d, n) && dalloc(pt.st.sh_c, n) && dalloc(pt.d_queue[0], n) &&
+                        dalloc(pt.d_queue[1], n) && dalloc(pt.d_acc, (size_t)n_slots * 3);
+        if (!ok) {
+            free_wavefront(pt);
+            return c->fail(RT_ERR_OOM, "wavefront buffers for %llu paths", (unsigned long long)n_paths);
+        }
+        pt.cap_paths = n_paths;
+        pt.cap_slots = n_slots;
+    }
+    return RT_OK;
+}
+
+rt::PtScene scene_view(const PtData& pt) {
+    rt::PtScene s{};
+    s.nodes = pt.d_nodes;
+    s.tris = pt.d_tris;
+    s.albedo = pt.d_albedo;
+    s.emission = pt.d_emission;
+    s.lights = pt.d_lights;
+    s.n_lights = pt.n_lights;
+    s.n_tris = pt.n_tris;
+    return s;
+}
+
+uint32_t owned_tiles(const rt::Partition& p) {
+    const uint32_t total = p.tiles_x * p.tiles_y;
+    return total > p.rank ? (total - p.rank + p.n_ranks - 1u) / p.n_ranks : 0u;
+}
+
+struct StageTimer {  // HIP-event pairs around launches, summed per stage after the frame
+    Ctx* c;
+    bool on;
+    std::vector<hipEvent_t>& pool;
+    std::vector<std::pair<int, size_t>> marks;  // stage, index of begin event
+    size_t used = 0;
+    hipEvent_t next() {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+    void begin(int stage) {
+        if (!on) return;
+        marks.push_back({stage, used});
+        hipEvent_t e = next();
+        if (e) (void)hipEventRecord(e, c->stream);
+    }
+    void end() {
+        if (!on) return;
+        hipEvent_t e = next();
+        if (e) (void)hipEventRecord(e, c->stream);
+    }
+};
+
+int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt_params* prm, float* dst_dev, int tile_major, bool sync) {
+    if (!c) return RT_ERR_INVALID;
+    if (!rot || !pos || !prm) return c->fail(RT_ERR_INVALID, "rot/pos/params must not be NULL");
+    if (!c->pt.n_tris) return c->fail(RT_ERR_STATE, "rt_set_mesh has not been called");
+    if (!c->width) return c->fail(RT_ERR_STATE, "rt_resize has not been called");
+    if (prm->spp == 0 || prm->bounces > kMaxBounces) return c->fail(RT_ERR_INVALID, "spp %u / bounces %u out of range", prm->spp, prm->bounces);
+    if (int rc = bind(c)) return rc;
+    PtData& pt = c->pt;
+
+    const uint32_t owned = owned_tiles(c->part);
+    const uint64_t n_slots = (uint64_t)owned * RT_TILE * RT_TILE;
+    if (n_slots == 0) return RT_OK;
+    if (n_slots > kMaxPathsInFlight) return c->fail(RT_ERR_INVALID, "view too large for one rank");
+    const uint64_t max_paths = prm->max_paths ? std::min<uint64_t>(prm->max_paths, kMaxPathsInFlight) : kMaxPathsInFlight;
+    const uint32_t spp_batch = (uint32_t)std::min<uint64_t>(prm->spp, std::max<uint64_t>(1, max_paths / n_slots));
+    if (int rc = ensure_wavefront(c, n_slots * spp_batch, n_slots)) return rc;
+
+    const rt::PtScene sc = scene_view(pt);
+    const bool count = prm->count_traversal != 0;
+    // persistent grid: enough 256-thread workgroups to fill every CU at the LDS-limited occupancy
+    const uint32_t grid_persistent = (uint32_t)c->n_cus * 5u;
+    const uint32_t grid_stride = (uint32_t)c->n_cus * 8u;
+
+    static thread_local std::vector<hipEvent_t> ev_pool;
+    StageTimer tm{c, c->cfg.profile_stages != 0, ev_pool, {}, 0};
+
+    RT_HIP(c, hipMemsetAsync(pt.d_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
+    uint64_t cam = 0, bnc = 0, shd = 0;
+    uint32_t launches_closest = 0, launches_shadow = 0;
+    std::vector<uint32_t> h_ctr((size_t)rt::PT_CTR_STRIDE * (prm->bounces + 2));
+
+    for (uint32_t s0 = 0; s0 < prm->spp; s0 += spp_batch) {
+        const uint32_t nb = std::min(spp_batch, prm->spp - s0);
+        rt::PtFrame f{};
+        std::memcpy(f.cam.rot, rot, 16);
+        std::memcpy(f.cam.pos, pos, 12);
+        f.cam.ratio[0] = c->ratio[0];
+        f.cam.ratio[1] = c->ratio[1];
+        f.width = c->width;
+        f.height = c->height;
+        f.part = c->part;
+        f.n_slots = (uint32_t)n_slots;
+        f.spp_batch = nb;
+        f.n_paths = (uint32_t)(n_slots * nb);
+        f.sample0 = s0;
+        f.spp_total = prm->spp;
+        f.bounces = prm->bounces;
+        f.seed = prm->seed;
+        std::memcpy(f.sky, prm->sky, 12);
+        f.ray_eps = prm->ray_eps;
+
+        const size_t ctr_words = (size_t)rt::PT_CTR_STRIDE * (prm->bounces + 2);
+        RT_HIP(c, hipMemsetAsync(pt.d_ctr, 0, ctr_words * sizeof(uint32_t), c->stream));
+        tm.begin(0);
+        if (int rc = rt::launch_pt_generate(c, f, pt.st, pt.d_queue[0], pt.d_ctr)) return rc;
+        tm.end();
+        for (uint32_t d = 0; d <= prm->bounces; d++) {
+            uint32_t* ctr_d = pt.d_ctr + (size_t)rt::PT_CTR_STRIDE * d;
+            uint32_t* ctr_n = pt.d_ctr + (size_t)rt::PT_CTR_STRIDE * (d + 1);
+            const uint32_t* q = pt.d_queue[d & 1];
+            uint32_t* qn = pt.d_queue[(d + 1) & 1];
+            tm.begin(1);
+            if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent)) return rc;
+            tm.end();
+            launches_closest++;
+            tm.begin(2);
+            if (int rc = rt::launch_pt_shade(c, sc, f, pt.st, q, ctr_d + rt::PT_CTR_COUNT, d, qn, ctr_n, grid_stride)) return rc;
+            tm.end();
+            if (pt.n_lights) {
+                tm.begin(3);
+                if (int rc = rt::launch_pt_trace(c, sc, pt.st, nullptr, ctr_n + rt::PT_CTR_SHADOW_COUNT, ctr_n + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, true, count, grid_persistent)) return rc;
+                tm.end();
+                launches_shadow++;
+            }
+        }
+        tm.begin(4);
+        if (int rc = rt::launch_pt_resolve(c, f, pt.st, pt.d_acc, dst_dev, tile_major)) return rc;
+        tm.end();
+        if (sync) {  // ray counters of this batch (the copy is ordered after the kernels on the stream)
+            RT_HIP(c, hipMemcpyAsync(h_ctr.data(), pt.d_ctr, ctr_words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            RT_HIP(c, hipStreamSynchronize(c->stream));
+            cam += h_ctr[rt::PT_CTR_COUNT];
+            for (uint32_t d = 1; d <= prm->bounces + 1; d++) {
+                if (d <= prm->bounces) bnc += h_ctr[(size_t)rt::PT_CTR_STRIDE * d + rt::PT_CTR_COUNT];
+                shd += h_ctr[(size_t)rt::PT_CTR_STRIDE * d + rt::PT_CTR_SHADOW_COUNT];
+            }
+        }
+    }
+    RT_HIP(c, hipEventRecord(c->ev_end, c->stream));
+    c->frame_valid = true;
+    pt.stats.launches_trace_closest = launches_closest;
+    pt.stats.launches_trace_shadow = launches_shadow;
+    if (sync) {
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        unsigned long long st[4] = {};
+        RT_HIP(c, hipMemcpy(st, pt.d_stats, sizeof st, hipMemcpyDeviceToHost));
+        pt.stats.camera_rays = cam;
+        pt.stats.bounce_rays = bnc;
+        pt.stats.shadow_rays = shd;
+        pt.stats.nodes_visited = st[0];
+        pt.stats.tris_tested = st[1];
+        pt.stats.stack_overflow = (uint32_t)st[2];
+        RT_HIP(c, hipEventElapsedTime(&pt.stats.ms_total, c->ev_begin, c->ev_end));
+        float sums[5] = {};
+        if (tm.on) {
+            for (auto& m : tm.marks) {
+                float ms = 0.0f;
+                if (m.second + 1 < tm.used && hipEventElapsedTime(&ms, ev_pool[m.second], ev_pool[m.second + 1]) == hipSuccess) sums[m.first] += ms;
+            }
+        }
+        pt.stats.ms_generate = sums[0];
+        pt.stats.ms_trace_closest = sums[1];
+        pt.stats.ms_shade = sums[2];
+        pt.stats.ms_trace_shadow = sums[3];
+        pt.stats.ms_resolve = sums[4];
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+namespace rt {
+void pt_free(Ctx* c) {
+    free_wavefront(c->pt);
+    free_mesh(c->pt);
+    dfree(c->pt.d_ctr);
+    dfree(c->pt.d_stats);
+}
+}  // namespace rt
+
+extern "C" {
+
+int rt_default_pt_params(rt_pt_params* p) {
+    if (!p) return RT_ERR_INVALID;
+    p->spp = 4;
+    p->bounces = 1;
+    p->seed = 1;
+    p->sky[0] = p->sky[1] = p->sky[2] = 0.0f;
+    p->ray_eps = 1e-3f;
+    p->count_traversal = 0;
+    p->max_paths = 0;
+    return RT_OK;
+}
+
+int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const float* emission, uint32_t n_tris) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return RT_ERR_INVALID;
+    if (!verts || !albedo || !emission) return c->fail(RT_ERR_INVALID, "mesh arrays must not be NULL");
+    if (n_tris == 0 || n_tris >= (1u << 28)) return c->fail(RT_ERR_INVALID, "n_tris %u out of [1, 2^28)", n_tris);
+    for (size_t i = 0; i < (size_t)n_tris * 9; i++)
+        if (!std::isfinite(verts[i])) return c->fail(RT_ERR_INVALID, "vertex data is not finite at float %zu", i);
+    if (int rc = bind(c)) return rc;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    PtData& pt = c->pt;
+    free_mesh(pt);
+
+    const size_t n = n_tris;
+    // spec §6.1: edges are formed once, in fp32
+    std::vector<float> v0(3 * n), e1(3 * n), e2(3 * n);
+    for (size_t i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) {
+            v0[3 * i + a] = verts[9 * i + a];
+            e1[3 * i + a] = verts[9 * i + 3 + a] - verts[9 * i + a];
+            e2[3 * i + a] = verts[9 * i + 6 + a] - verts[9 * i + a];
+        }
+    const auto t0 = std::chrono::steady_clock::now();
+    rt::BvhResult bvh;
+    if (!rt::build_bvh(v0.data(), e1.data(), e2.data(), n_tris, rt::kBvhMaxDepth, &bvh)) return c->fail(RT_ERR_INVALID, "BVH build failed");
+    pt.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+    // leaf-order triangle records + materials; lights in ascending original index
+    std::vector<float> tris(12 * n), alb(4 * n), emi(4 * n);
+    std::vector<uint32_t> leaf_pos(n);
+    for (size_t li = 0; li < n; li++) {
+        const uint32_t t = bvh.order[li];
+        leaf_pos[t] = (uint32_t)li;
+        float* r = &tris[12 * li];
+        r[0] = v0[3 * t]; r[1] = v0[3 * t + 1]; r[2] = v0[3 * t + 2]; r[3] = e1[3 * t];
+        r[4] = e1[3 * t + 1]; r[5] = e1[3 * t + 2]; r[6] = e2[3 * t]; r[7] = e2[3 * t + 1];
+        r[8] = e2[3 * t + 2];
+        std::memcpy(&r[9], &t, 4);
+        r[10] = r[11] = 0.0f;
+        for (int a = 0; a < 3; a++) {
+            alb[4 * li + a] = albedo[3 * (size_t)t + a];
+            emi[4 * li + a] = emission[3 * (size_t)t + a];
+        }
+        alb[4 * li + 3] = emi[4 * li + 3] = 0.0f;
+    }
+    std::vector<uint32_t> lights;
+    for (size_t t = 0; t < n; t++)
+        if (emission[3 * t] > 0.0f || emission[3 * t + 1] > 0.0f || emission[3 * t + 2] > 0.0f) lights.push_back(leaf_pos[t]);
+
+    const bool ok = dalloc(pt.d_nodes, (size_t)bvh.n_nodes * 4) && dalloc(pt.d_tris, n * 3) && dalloc(pt.d_albedo, n) && dalloc(pt.d_emission, n) &&
+                    dalloc(pt.d_lights, std::max<size_t>(lights.size(), 1));
+    if (!ok) {
+        free_mesh(pt);
+        return c->fail(RT_ERR_OOM, "mesh of %u triangles", n_tris);
+    }
+    RT_HIP(c, hipMemcpy(pt.d_nodes, bvh.nodes.data(), (size_t)bvh.n_nodes * 64, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(pt.d_tris, tris.data(), n * 48, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(pt.d_albedo, alb.data(), n * 16, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(pt.d_emission, emi.data(), n * 16, hipMemcpyHostToDevice));
+    if (!lights.empty()) RT_HIP(c, hipMemcpy(pt.d_lights, lights.data(), lights.size() * 4, hipMemcpyHostToDevice));
+    pt.n_tris = n_tris;
+    pt.n_nodes = bvh.n_nodes;
+    pt.n_lights = (uint32_t)lights.size();
+    pt.bvh_depth = bvh.depth;
+    pt.bvh_pad = bvh.pad;
+    pt.stats = rt_pt_stats{};
+    pt.stats.n_tris = n_tris;
+    pt.stats.n_nodes = bvh.n_nodes;
+    pt.stats.bvh_depth = bvh.depth;
+    pt.stats.n_lights = pt.n_lights;
+    pt.stats.bvh_build_ms = pt.bvh_build_ms;
+    return RT_OK;
+}
+
+int rt_render_pt(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, float* rgb_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return RT_ERR_INVALID;
+    if (!c->width) return c->fail(RT_ERR_STATE, "rt_resize has not been called");
+    if (int rc = bind(c)) return rc;
+    RT_HIP(c, hipMemsetAsync(c->d_rgb, 0, (size_t)c->width * c->height * 3 * sizeof(float), c->stream));
+    if (int rc = render_pt_common(c, rot, pos, params, c->d_rgb, 0, true)) return rc;
+    if (rgb_out) RT_HIP(c, hipMemcpy(rgb_out, c->d_rgb, (size_t)c->width * c->height * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_render_pt_device(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, void* rgb_dev, int tile_major) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return RT_ERR_INVALID;
+    if (!rgb_dev) return c->fail(RT_ERR_INVALID, "rgb_dev is NULL");
+    return render_pt_common(c, rot, pos, params, static_cast<float*>(rgb_dev), tile_major, false);
+}
+
+int rt_get_pt_stats(rt_ctx* ctx, rt_pt_stats* stats) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !stats) return RT_ERR_INVALID;
+    *stats = c->pt.stats;
+    return RT_OK;
+}
+
+int rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int32_t* tri_out) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return RT_ERR_INVALID;
+    if (!origins || !dirs || !t_out || !tri_out) return c->fail(RT_ERR_INVALID, "NULL ray buffer");
+    if (!c->pt.n_tris) return c->fail(RT_ERR_STATE, "rt_set_mesh has not been called");
+    if (n == 0) return RT_OK;
+    if (int rc = bind(c)) return rc;
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    int* d_i = nullptr;
+    const size_t nb = (size_t)n;
+    int rc = RT_OK;
+    if (!dalloc(d_o, nb * 3) || !dalloc(d_d, nb * 3) || !dalloc(d_t, nb) || !dalloc(d_i, nb)) rc = c->fail(RT_ERR_OOM, "ray buffers");
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpy(d_o, origins, nb * 12, hipMemcpyHostToDevice);
+    if (!rc && e == hipSuccess) e = hipMemcpy(d_d, dirs, nb * 12, hipMemcpyHostToDevice);
+    if (!rc && e == hipSuccess) rc = rt::launch_pt_trace_rays(c, scene_view(c->pt), d_o, d_d, n, any_hit, d_t, d_i);
+    if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (!rc && e == hipSuccess) e = hipMemcpy(t_out, d_t, nb * 4, hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess) e = hipMemcpy(tri_out, d_i, nb * 4, hipMemcpyDeviceToHost);
+    dfree(d_o);
+    dfree(d_d);
+    dfree(d_t);
+    dfree(d_i);
+    if (rc) return rc;
+    if (e != hipSuccess) return c->fail(RT_ERR_HIP, "rt_trace_rays: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"

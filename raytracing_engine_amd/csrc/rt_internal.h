@@ -75,6 +75,65 @@ struct ShadeParams {
     float spp;
 };
 
+// ---- path B (triangles + BVH + path tracing) -------------------------------------
+enum { PT_CTR_COUNT = 0, PT_CTR_SHADOW_COUNT = 1, PT_CTR_HEAD_CLOSEST = 2, PT_CTR_HEAD_SHADOW = 3, PT_CTR_STRIDE = 4 };
+
+struct PtScene {
+    const float4* nodes;     // 4 x float4 per BVH node (bvh_build.cpp layout)
+    const float4* tris;      // 3 x float4 per triangle, leaf order: v0.xyz e1.x | e1.yz e2.xy | e2.z id - -
+    const float4* albedo;    // leaf order
+    const float4* emission;  // leaf order
+    const uint32_t* lights;  // leaf-order indices of emissive triangles, ascending original id
+    uint32_t n_lights;
+    uint32_t n_tris;
+};
+
+struct PtState {  // SoA over path ids; one float4 per lane per array = 16-byte coalesced accesses
+    float4* ray_o;
+    float4* ray_d;
+    float4* thr;   // path throughput
+    float4* rad;   // accumulated radiance of the path
+    float2* hit;   // t, leaf-order triangle index (int bits, -1 = miss)
+    float4* sh_o;  // shadow queue: origin.xyz, path id bits
+    float4* sh_d;  // shadow queue: unnormalised direction to the light sample
+    float4* sh_c;  // shadow queue: contribution if unoccluded
+};
+
+struct PtFrame {
+    Camera cam;
+    uint32_t width, height;
+    Partition part;
+    uint32_t n_slots;    // owned tiles * 4096
+    uint32_t n_paths;    // n_slots * spp_batch
+    uint32_t spp_batch;  // samples in flight per pixel in this pass
+    uint32_t sample0;    // first sample index of this pass
+    uint32_t spp_total;
+    uint32_t bounces;
+    uint32_t seed;
+    float sky[3];
+    float ray_eps;
+};
+
+struct PtData {  // device residency of one mesh + the wavefront buffers
+    uint32_t n_tris = 0, n_nodes = 0, n_lights = 0, bvh_depth = 0;
+    float bvh_build_ms = 0.0f, bvh_pad = 0.0f;
+    float4* d_nodes = nullptr;
+    float4* d_tris = nullptr;
+    float4* d_albedo = nullptr;
+    float4* d_emission = nullptr;
+    uint32_t* d_lights = nullptr;
+    // wavefront buffers, sized for cap_paths
+    uint64_t cap_paths = 0;
+    uint32_t cap_depth = 0;
+    PtState st{};
+    uint32_t* d_queue[2] = {nullptr, nullptr};
+    uint32_t* d_ctr = nullptr;
+    unsigned long long* d_stats = nullptr;
+    float* d_acc = nullptr;  // per-slot running sums across sample batches
+    uint64_t cap_slots = 0;
+    rt_pt_stats stats{};
+};
+
 struct Ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
@@ -98,6 +157,8 @@ struct Ctx {
     std::vector<hipEvent_t> ev_stage;  // profile_stages
     rt_stats stats{};
     bool frame_valid = false;
+    PtData pt;
+    int n_cus = 256;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -123,5 +184,16 @@ int launch_shade(Ctx* c, const ShadeSet& set, uint32_t n_obj, const ShadeParams&
                  uint64_t* counters);
 int launch_detile(Ctx* c, const float* tiles, uint32_t n_ranks, uint32_t tiles_per_rank, float* rgb);
 int launch_to_rgba8(Ctx* c, const float* rgb, uint8_t* rgba, uint64_t n_pixels);
+
+// path_b.hip
+int launch_pt_generate(Ctx* c, const PtFrame& f, const PtState& st, uint32_t* queue, uint32_t* ctr);
+int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head,
+                    unsigned long long* stats, bool any_hit, bool count, uint32_t grid);
+int launch_pt_shade(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr,
+                    uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid);
+int launch_pt_resolve(Ctx* c, const PtFrame& f, const PtState& st, float* acc, float* dst, int tile_major);
+int launch_pt_trace_rays(Ctx* c, const PtScene& sc, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out,
+                         int* tri_out);
+void pt_free(Ctx* c);
 
 }  // namespace rt

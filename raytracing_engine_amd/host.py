@@ -8,7 +8,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import Config, Light, Material, MutableData, Object, RtError, Stats
+from ._lib import Config, Light, Material, MutableData, Object, PtParams, PtStats, RtError, Stats
 
 # src/main.rs:343-364
 SPEED_MOVEMENT = 25.0
@@ -233,6 +233,52 @@ class Renderer:
         s = Stats()
         self._check(self._lib.rt_get_stats(self._ctx, C.byref(s)))
         return s.as_dict()
+
+    # ---- path B: triangle mesh + BVH + wavefront path tracer (no reference counterpart) ----------
+    def set_mesh(self, verts, albedo, emission):
+        verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 9)
+        albedo = np.ascontiguousarray(albedo, np.float32).reshape(-1, 3)
+        emission = np.ascontiguousarray(emission, np.float32).reshape(-1, 3)
+        if not (len(verts) == len(albedo) == len(emission)):
+            raise ValueError("verts/albedo/emission disagree on the triangle count")
+        self._check(self._lib.rt_set_mesh(self._ctx, _fptr(verts), _fptr(albedo), _fptr(emission), len(verts)))
+
+    def pt_params(self, spp=4, bounces=1, seed=1, sky=(0.0, 0.0, 0.0), ray_eps=1e-3, count_traversal=False, max_paths=0):
+        p = PtParams()
+        self._lib.rt_default_pt_params(C.byref(p))
+        p.spp, p.bounces, p.seed, p.ray_eps, p.count_traversal, p.max_paths = spp, bounces, seed, ray_eps, int(count_traversal), max_paths
+        p.sky[:] = [float(np.float32(x)) for x in sky]
+        return p
+
+    def render_pt(self, rot=(0, 0, 0, 1), pos=(0, 0, 0), params=None, **kw):
+        """Synchronous path-traced frame -> (H,W,3) f32."""
+        params = params or self.pt_params(**kw)
+        rot = np.ascontiguousarray(rot, np.float32)
+        pos = np.ascontiguousarray(pos, np.float32)
+        rgb = np.empty((self.height, self.width, 3), np.float32)
+        self._check(self._lib.rt_render_pt(self._ctx, _fptr(rot), _fptr(pos), C.byref(params), _fptr(rgb)))
+        return rgb
+
+    def render_pt_device(self, rot, pos, params, dev_ptr, tile_major=False):
+        rot = np.ascontiguousarray(rot, np.float32)
+        pos = np.ascontiguousarray(pos, np.float32)
+        self._check(self._lib.rt_render_pt_device(self._ctx, _fptr(rot), _fptr(pos), C.byref(params), C.c_void_p(dev_ptr), int(tile_major)))
+
+    def pt_stats(self):
+        s = PtStats()
+        self._check(self._lib.rt_get_pt_stats(self._ctx, C.byref(s)))
+        return s.as_dict()
+
+    def trace_rays(self, origins, dirs, any_hit=False):
+        """Test hook: closest hit (t, original triangle index) or occlusion flags for a ray batch."""
+        origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(origins)
+        t = np.empty(n, np.float32)
+        tri = np.empty(n, np.int32)
+        self._check(self._lib.rt_trace_rays(self._ctx, _fptr(origins), _fptr(dirs), n, int(any_hit), _fptr(t),
+                                            tri.ctypes.data_as(C.POINTER(C.c_int32))))
+        return t, tri
 
 
 def tile_owner(tile_index, n_ranks):
