@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="spheres8_1080p_4spp")
+    ap.add_argument("--workload", default="tri1m_1080p_4spp", help="tri1m_1080p_4spp (metric config) | spheres8_1080p_4spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -130,7 +130,95 @@ class SpheresWorkload:
                           f"(OpenMP, {threads} threads), {dt:.2f} s"}
 
 
-WORKLOADS = {SpheresWorkload.name: SpheresWorkload}
+class TriWorkload:
+    """BASELINE.json metric config: 1 M-triangle BVH scene, 1920x1080, 4 spp, path B (wavefront path
+    tracer: camera ray + next-event shadow ray + 1 diffuse bounce with its own shadow ray).  Build-
+    defined extension: the reference has no triangles/BVH, parity is against oracle B only."""
+
+    name = "tri1m_1080p_4spp"
+    n_tris, edge = 1_000_000, 0.08
+    width, height, spp, bounces, seed = 1920, 1080, 4, 1, 1
+    sky = (0.2, 0.2, 0.25)
+    dtype = "f32"
+
+    def __init__(self, R, renderer):
+        self.R, self.r = R, renderer
+        self.mesh = R.scenes.soup_scene(self.n_tris, seed=1, edge=self.edge)
+        self.rot = np.array([0, 0, 0, 1], np.float32)
+        self.pos = np.zeros(3, np.float32)
+        renderer.set_mesh(*self.mesh)
+        renderer.resize(self.width, self.height)
+        self.params = renderer.pt_params(spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky)
+
+    def describe(self):
+        st = self.r.pt_stats()
+        return {"workload": f"{self.name}: {self.n_tris} random triangles (edge +-{self.edge}) + 1 emissive quad, BVH2 "
+                            f"({st['n_nodes']} nodes, depth {st['bvh_depth']}), {self.width}x{self.height}, {self.spp} spp, "
+                            f"{self.bounces} bounce + NEE, path B wavefront path tracer",
+                "width": self.width, "height": self.height, "spp": self.spp, "bounces": self.bounces, "tile": 64,
+                "bvh_build_ms_host": round(st["bvh_build_ms"], 1)}
+
+    def step(self, out_ptr, tile_major):
+        self.r.render_pt_device(self.rot, self.pos, self.params, out_ptr, tile_major)
+
+    def rays_per_step(self):
+        self.r.render_pt(self.rot, self.pos, params=self.params)
+        st = self.r.pt_stats()
+        return st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
+
+    def roofline(self):
+        """Dominant kernel = pt_trace<closest>.  Algorithmic bytes per launch: every BVH
+        node fetched = 64 B, every triangle tested = 48 B, per ray 32 B ray read + 8 B hit write + 4 B
+        queue entry; counts come from the kernel's own instrumented twin (count_traversal)."""
+        r = self.r
+        prm = r.pt_params(spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky, count_traversal=True)
+        r.render_pt(self.rot, self.pos, params=prm)
+        ct = r.pt_stats()
+        cfg = r.default_config()
+        cfg.profile_stages = 1
+        r.set_config(cfg)
+        reps = 5
+        acc = {k: 0.0 for k in ("ms_generate", "ms_trace_closest", "ms_shade", "ms_trace_shadow", "ms_resolve", "ms_total")}
+        for _ in range(reps):
+            r.render_pt(self.rot, self.pos, params=self.params)
+            st = r.pt_stats()
+            for k in acc:
+                acc[k] += st[k] / reps
+        cfg.profile_stages = 0
+        r.set_config(cfg)
+        closest_rays = ct["camera_rays"] + ct["bounce_rays"]
+        bytes_closest = ct["nodes_visited"] * 64.0 + ct["tris_tested"] * 48.0 + closest_rays * 44.0
+        bytes_shadow = ct["shadow_nodes_visited"] * 64.0 + ct["shadow_tris_tested"] * 48.0 + ct["shadow_rays"] * 48.0
+        n_launch = st["launches_trace_closest"]
+        ms = acc["ms_trace_closest"] / n_launch
+        achieved = bytes_closest / (acc["ms_trace_closest"] * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "pt_trace<closest>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_kernel_ms": round(ms, 4), "launches_per_step": n_launch,
+                "algorithmic_bytes_per_launch": bytes_closest / n_launch,
+                "per_ray": {"nodes": round(ct["nodes_visited"] / closest_rays, 2), "tris": round(ct["tris_tested"] / closest_rays, 2),
+                            "bytes": round(bytes_closest / closest_rays, 1),
+                            "shadow_nodes": round(ct["shadow_nodes_visited"] / max(ct["shadow_rays"], 1), 2),
+                            "shadow_bytes": round(bytes_shadow / max(ct["shadow_rays"], 1), 1)},
+                "stage_ms": {k: round(v, 4) for k, v in acc.items()},
+                "shadow_kernel_GBs": round(bytes_shadow / max(acc["ms_trace_shadow"], 1e-9) / 1e6, 1)}
+
+    def cpu_baseline(self):
+        import oracle as O
+
+        threads = host_threads()
+        sc = O.TriScene(*self.mesh)
+        w, h = self.width, self.height  # the full workload, once
+        sc.render(32, 18, spp=1, bounces=self.bounces, seed=self.seed, sky=self.sky, threads=threads)
+        t0 = time.perf_counter()
+        _, ct = sc.render(w, h, spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky, rot=self.rot, pos=self.pos, threads=threads)
+        dt = time.perf_counter() - t0
+        rays = ct["camera_rays"] + ct["bounce_rays"] + ct["shadow_rays"]
+        return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                "sample": f"the full workload once ({w}x{h}, {self.spp} spp, same scene/camera/seed), oracle B with its own "
+                          f"median-split BVH (OpenMP, {threads} threads), {rays} rays in {dt:.2f} s"}
+
+
+WORKLOADS = {SpheresWorkload.name: SpheresWorkload, TriWorkload.name: TriWorkload}
 
 
 def main():

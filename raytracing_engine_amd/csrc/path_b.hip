@@ -281,8 +281,8 @@ __global__ __launch_bounds__(256) void pt_trace(const PtScene sc, PtState st, co
             b += __shfl_down(b, off);
         }
         if (lane == 0) {
-            atomicAdd(&stats[0], a);
-            atomicAdd(&stats[1], b);
+            atomicAdd(&stats[ANY ? 4 : 0], a);
+            atomicAdd(&stats[ANY ? 5 : 1], b);
         }
     }
     if (overflow) atomicOr((unsigned int*)&stats[2], 1u);

@@ -61,7 +61,7 @@ bool dalloc(T*& p, size_t count) {
 int ensure_wavefront(Ctx* c, uint64_t n_paths, uint64_t n_slots) {
     PtData& pt = c->pt;
     if (!pt.d_ctr) {
-        if (!dalloc(pt.d_ctr, (size_t)rt::PT_CTR_STRIDE * (kMaxBounces + 3)) || !dalloc(pt.d_stats, 4)) return c->fail(RT_ERR_OOM, "path-tracer counters");
+        if (!dalloc(pt.d_ctr, (size_t)rt::PT_CTR_STRIDE * (kMaxBounces + 3)) || !dalloc(pt.d_stats, 8)) return c->fail(RT_ERR_OOM, "path-tracer counters");
     }
     if (n_paths > pt.cap_paths || n_slots > pt.cap_slots) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -150,7 +150,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     static thread_local std::vector<hipEvent_t> ev_pool;
     StageTimer tm{c, c->cfg.profile_stages != 0, ev_pool, {}, 0};
 
-    RT_HIP(c, hipMemsetAsync(pt.d_stats, 0, 4 * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipMemsetAsync(pt.d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     uint64_t cam = 0, bnc = 0, shd = 0;
     uint32_t launches_closest = 0, launches_shadow = 0;
@@ -219,13 +219,15 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     pt.stats.launches_trace_shadow = launches_shadow;
     if (sync) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
-        unsigned long long st[4] = {};
+        unsigned long long st[8] = {};
         RT_HIP(c, hipMemcpy(st, pt.d_stats, sizeof st, hipMemcpyDeviceToHost));
         pt.stats.camera_rays = cam;
         pt.stats.bounce_rays = bnc;
         pt.stats.shadow_rays = shd;
         pt.stats.nodes_visited = st[0];
         pt.stats.tris_tested = st[1];
+        pt.stats.shadow_nodes_visited = st[4];
+        pt.stats.shadow_tris_tested = st[5];
         pt.stats.stack_overflow = (uint32_t)st[2];
         RT_HIP(c, hipEventElapsedTime(&pt.stats.ms_total, c->ev_begin, c->ev_end));
         float sums[5] = {};
