@@ -167,10 +167,14 @@ typedef struct rt_pt_params {
     float ray_eps;     /* origin offset along the shading normal (default 1e-3) */
     uint32_t count_traversal; /* 1: count BVH nodes fetched / triangles tested (rt_pt_stats) */
     uint32_t max_paths;       /* cap on paths in flight per pass (0 = default 2^25); spp is split into passes */
+    uint32_t tune_refill_min;    /* tuning: idle lanes per wave that trigger a refill (0 = default 16) */
+    uint32_t tune_blocks_per_cu; /* tuning: persistent workgroups per CU (0 = as many as the LDS stacks allow) */
+    uint32_t tune_lds_stack;     /* tuning: traversal-stack entries kept in LDS per lane (0 = default 16), rest spills */
 } rt_pt_params;
 
 typedef struct rt_pt_stats {
-    uint32_t n_tris, n_nodes, bvh_depth, n_lights;
+    uint32_t n_tris, n_nodes, bvh_depth, n_lights; /* n_nodes / bvh_depth of the 4-wide BVH */
+    uint32_t stack_need;       /* worst-case traversal stack entries for this BVH */
     float bvh_build_ms;
     uint32_t stack_overflow;   /* must be 0: traversal stack never exceeded */
     uint64_t camera_rays, bounce_rays, shadow_rays; /* last render: rays handed to BVH traversal */

@@ -61,12 +61,13 @@ class Stats(C.Structure):
 
 class PtParams(C.Structure):  # rt_pt_params
     _fields_ = [("spp", C.c_uint32), ("bounces", C.c_uint32), ("seed", C.c_uint32), ("sky", C.c_float * 3),
-                ("ray_eps", C.c_float), ("count_traversal", C.c_uint32), ("max_paths", C.c_uint32)]
+                ("ray_eps", C.c_float), ("count_traversal", C.c_uint32), ("max_paths", C.c_uint32),
+                ("tune_refill_min", C.c_uint32), ("tune_blocks_per_cu", C.c_uint32), ("tune_lds_stack", C.c_uint32)]
 
 
 class PtStats(C.Structure):  # rt_pt_stats
     _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("n_lights", C.c_uint32),
-                ("bvh_build_ms", C.c_float), ("stack_overflow", C.c_uint32), ("camera_rays", C.c_uint64),
+                ("stack_need", C.c_uint32), ("bvh_build_ms", C.c_float), ("stack_overflow", C.c_uint32), ("camera_rays", C.c_uint64),
                 ("bounce_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("tris_tested", C.c_uint64), ("shadow_nodes_visited", C.c_uint64), ("shadow_tris_tested", C.c_uint64),
                 ("ms_total", C.c_float), ("ms_generate", C.c_float),

@@ -5,10 +5,16 @@
 // (boxes are padded conservatively, closest hit = lexicographic (t, triangle id) minimum), so the
 // builder is free to optimise for traversal cost only.
 //
+// The binary SAH tree is collapsed into a 4-wide BVH: traversal on gfx950 is bound by the latency of
+// dependent node fetches (L2 / Infinity-Cache round trips), so halving the number of levels matters
+// more than the extra box tests per step.
+//
 // Output layout, sized for per-lane gathers on gfx950:
-//   nodes: one 64-byte record per inner node = 4 x float4, both children's boxes in one fetch
-//       q0 = lo0.xyz, hi0.x   q1 = hi0.yz, lo1.xy   q2 = lo1.z, hi1.xyz   q3 = ref0, ref1, -, -
-//       ref >= 0: inner node index; ref < 0: leaf, ~ref = (first << 2) | (count - 1), count <= 4
+//   nodes: one 128-byte record (= one L2 line) per inner node = 8 x float4, children planar (SoA):
+//       q0 = lo.x[0..3]  q1 = lo.y[0..3]  q2 = lo.z[0..3]  q3 = hi.x[0..3]  q4 = hi.y[0..3]  q5 = hi.z[0..3]
+//       q6 = ref[0..3]   q7 = unused
+//       ref >= 0: inner node index; ref < 0: leaf, ~ref = (first << 2) | (count - 1), count <= 4;
+//       ref == 0x80000000: empty slot (its box is a far-away point no ray reaches)
 //   order: leaf-order position -> original triangle index (triangle records are stored in leaf order
 //       so a leaf's triangles are contiguous)
 #include "bvh_build.h"
@@ -48,7 +54,6 @@ struct Box {
 };
 
 constexpr int kBins = 16;
-constexpr uint32_t kLeafMax = 4;
 
 struct Builder {
     const std::vector<Box>& tri_box;
@@ -57,6 +62,7 @@ struct Builder {
     std::vector<float>& nodes;  // 16 floats per node
     float pad;
     uint32_t max_depth;
+    uint32_t kLeafMax = 4;
     uint32_t depth_reached = 0;
     double sah = 0.0;
 
@@ -70,7 +76,7 @@ struct Builder {
     static int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 2) | (count - 1u)); }
 
     // smallest depth a balanced tree needs for `count` triangles with leaves of kLeafMax
-    static uint32_t min_depth(uint32_t count) {
+    uint32_t min_depth(uint32_t count) const {
         uint32_t d = 0;
         uint64_t cap = kLeafMax;
         while (cap < count) {
@@ -189,6 +195,66 @@ struct Builder {
 
 }  // namespace
 
+namespace {
+
+constexpr int32_t kEmptyRef = (int32_t)0x80000000;
+
+struct Child {
+    float box[6];  // lo.xyz, hi.xyz (already padded)
+    int32_t ref;   // BVH2 ref
+    float area() const {
+        const float dx = box[3] - box[0], dy = box[4] - box[1], dz = box[5] - box[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Collapser {
+    const std::vector<float>& n2;  // 16 floats per binary node
+    std::vector<float>& n4;        // 32 floats per 4-wide node
+    uint32_t stack_need = 0, depth = 0;
+
+    void children_of(int32_t node2, Child out[2]) const {
+        const float* n = &n2[(size_t)node2 * 16];
+        std::memcpy(out[0].box, n, 24);
+        std::memcpy(out[1].box, n + 6, 24);
+        std::memcpy(&out[0].ref, n + 12, 4);
+        std::memcpy(&out[1].ref, n + 13, 4);
+    }
+
+    // below = stack entries already held when this node is entered (worst case)
+    int32_t collapse(int32_t node2, uint32_t below, uint32_t level) {
+        Child ch[4];
+        int k = 2;
+        children_of(node2, ch);
+        if (ch[0].ref < 0 && ch[0].ref == ch[1].ref) k = 1;  // tiny mesh: both binary slots name one leaf
+        while (k < 4) {  // open the inner child with the largest surface until 4 children
+            int best = -1;
+            for (int i = 0; i < k; i++)
+                if (ch[i].ref >= 0 && (best < 0 || ch[i].area() > ch[best].area())) best = i;
+            if (best < 0) break;
+            Child two[2];
+            children_of(ch[best].ref, two);
+            ch[best] = two[0];
+            ch[k++] = two[1];
+        }
+        const uint32_t me = (uint32_t)(n4.size() / 32);
+        n4.resize(n4.size() + 32);
+        const uint32_t held = below + (uint32_t)(k - 1);
+        stack_need = std::max(stack_need, held);
+        depth = std::max(depth, level + 1);
+        int32_t refs[4];
+        for (int i = 0; i < 4; i++) refs[i] = i < k ? (ch[i].ref < 0 ? ch[i].ref : collapse(ch[i].ref, held, level + 1)) : kEmptyRef;
+        float* n = &n4[(size_t)me * 32];
+        for (int i = 0; i < 4; i++)
+            for (int a = 0; a < 6; a++) n[a * 4 + i] = i < k ? ch[i].box[a] : 3.0e38f;
+        std::memcpy(n + 24, refs, 16);
+        n[28] = n[29] = n[30] = n[31] = 0.0f;
+        return (int32_t)me;
+    }
+};
+
+}  // namespace
+
 bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, uint32_t max_depth, BvhResult* out) {
     if (!v0 || !e1 || !e2 || n == 0 || n >= (1u << 29) || !out) return false;
     std::vector<Box> tri_box(n);
@@ -216,8 +282,9 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
     out->nodes.reserve(16 * (size_t)(n / 2 + 16));
     // conservative padding: absorbs the rounding of the slab test and of Moeller-Trumbore's t
     out->pad = 2e-5f * std::max(maxabs, 1.0f);
-    Builder b{tri_box, centroid, out->order, out->nodes, out->pad, max_depth};
-    if (n <= kLeafMax) {
+    const uint32_t leaf_max = std::min<uint32_t>(std::max<uint32_t>(out->leaf_max, 1u), 4u);
+    Builder b{tri_box, centroid, out->order, out->nodes, out->pad, max_depth, leaf_max};
+    if (n <= leaf_max) {
         // one node whose two slots name the same leaf (testing it twice is idempotent)
         out->nodes.resize(16);
         Box bx = b.range_box(0, n);
@@ -235,8 +302,16 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
         b.build(0, n, 0);
         out->depth = b.depth_reached + 1;
     }
-    out->n_nodes = (uint32_t)(out->nodes.size() / 16);
     out->sah_area = b.sah;
+    // collapse to 4-wide nodes
+    std::vector<float> binary;
+    binary.swap(out->nodes);
+    out->nodes.reserve(binary.size());
+    Collapser col{binary, out->nodes};
+    col.collapse(0, 0, 0);
+    out->n_nodes = (uint32_t)(out->nodes.size() / 32);
+    out->depth = col.depth;
+    out->stack_need = col.stack_need;
     return true;
 }
 

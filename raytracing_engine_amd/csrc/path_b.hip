@@ -23,7 +23,6 @@
 namespace rt {
 using namespace rtk;
 
-constexpr int kStack = 32;  // >= kBvhMaxDepth + 1 (bvh_build.h)
 constexpr int kSentinel = (int)0x80000000;
 constexpr float kShadowTmax = 0.999f;
 
@@ -96,14 +95,29 @@ __device__ __forceinline__ v3 safe_inv(v3 d) {
     return mk(1.0f / x, 1.0f / y, 1.0f / z);
 }
 
-// conservative slab test against a padded box
-__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, v3 o, v3 inv, float tmax,
-                                         float& tn) {
-    const float t0x = (lox - o.x) * inv.x, t1x = (hix - o.x) * inv.x;
-    const float t0y = (loy - o.y) * inv.y, t1y = (hiy - o.y) * inv.y;
-    const float t0z = (loz - o.z) * inv.z, t1z = (hiz - o.z) * inv.z;
+// A ray in traversal form.  The slab test uses t = lo*inv - o*inv (one fma per plane); boxes are
+// padded at build time, so this test only has to be conservative, not bit-identical to anything
+// (results do not depend on which boxes are visited).
+struct TRay {
+    v3 o, d, inv, noi;  // noi = -(o * inv)
+    float tmax;
+};
+__device__ __forceinline__ TRay make_tray(v3 o, v3 d, float tmax) {
+    TRay r;
+    r.o = o;
+    r.d = d;
+    r.inv = safe_inv(d);
+    r.noi = mk(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
+    r.tmax = tmax;
+    return r;
+}
+
+__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, const TRay& r, float& tn) {
+    const float t0x = __builtin_fmaf(lox, r.inv.x, r.noi.x), t1x = __builtin_fmaf(hix, r.inv.x, r.noi.x);
+    const float t0y = __builtin_fmaf(loy, r.inv.y, r.noi.y), t1y = __builtin_fmaf(hiy, r.inv.y, r.noi.y);
+    const float t0z = __builtin_fmaf(loz, r.inv.z, r.noi.z), t1z = __builtin_fmaf(hiz, r.inv.z, r.noi.z);
     tn = fmax_(fmax_(fmin_(t0x, t1x), fmin_(t0y, t1y)), fmax_(fmin_(t0z, t1z), 0.0f));
-    const float tf = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), tmax));
+    const float tf = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), r.tmax));
     return tn <= tf * 1.0000004f;
 }
 
@@ -113,62 +127,131 @@ struct Hit {
     uint32_t id;  // original triangle index (tie-break)
 };
 
-// BVH2 traversal, "while-while": descend through inner nodes until a leaf reference comes up, then
-// test its triangles.  `stack` points at this thread's column of the LDS stack (stride 256).
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris, v3 o, v3 d, int* stack,
-                                         Hit& best, uint32_t& n_nodes, uint32_t& n_tris, uint32_t& overflow) {
-    const v3 inv = safe_inv(d);
-    float tmax = ANY ? kShadowTmax : best.t;
-    int sp = 0;
-    int cur = 0;
-    while (cur != kSentinel) {
-        while (cur >= 0) {
-            const float4 q0 = nodes[(size_t)cur * 4 + 0], q1 = nodes[(size_t)cur * 4 + 1], q2 = nodes[(size_t)cur * 4 + 2],
-                         q3 = nodes[(size_t)cur * 4 + 3];
-            if (COUNT) n_nodes++;
-            float tn0, tn1;
-            const bool h0 = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tmax, tn0);
-            const bool h1 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tmax, tn1);
-            const int r0 = __float_as_int(q3.x), r1 = __float_as_int(q3.y);
-            if (h0 && h1) {
-                const bool swap = tn1 < tn0;
-                const int near = swap ? r1 : r0, far = swap ? r0 : r1;
-                if (sp < kStack) stack[(sp++) * 256] = far;
-                else overflow = 1;
-                cur = near;
-            } else if (h0) {
-                cur = r0;
-            } else if (h1) {
-                cur = r1;
-            } else {
-                cur = sp ? stack[(--sp) * 256] : kSentinel;
-            }
+struct TravCounters {
+    uint32_t nodes, tris, overflow;
+};
+
+// Per-lane traversal stack.  The first `lds_cap` entries live in LDS (column of this thread, stride
+// 256 ints: bank = lane, conflict-free); deeper entries - rare, the worst case of a 4-wide tree is
+// 3 entries per level - spill to a global column (entry-major, so a wave's spill is coalesced).
+// The builder reports the exact worst-case occupancy and the host sizes lds_cap + spill_cap to it.
+struct TravStack {
+    int* lds;
+    int* spill;
+    size_t spill_stride;
+    int lds_cap, spill_cap;
+    int sp;
+    __device__ __forceinline__ void push(int v, uint32_t& overflow) {
+        if (sp < lds_cap) lds[sp * 256] = v;
+        else if (sp - lds_cap < spill_cap) spill[(size_t)(sp - lds_cap) * spill_stride] = v;
+        else {
+            overflow = 1;
+            return;
         }
-        if (cur != kSentinel) {
-            const uint32_t ref = ~(uint32_t)cur;
-            const uint32_t first = ref >> 2, cnt = (ref & 3u) + 1u;
-            for (uint32_t i = 0; i < cnt; i++) {
-                const uint32_t li = first + i;
-                const float4 a = tris[(size_t)li * 3 + 0], b = tris[(size_t)li * 3 + 1], c = tris[(size_t)li * 3 + 2];
-                if (COUNT) n_tris++;
-                float t;
-                if (tri_test(o, d, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t) && t > 0.0f) {
-                    if (ANY) {
-                        if (t < kShadowTmax) return true;
-                    } else {
-                        const uint32_t id = __float_as_uint(c.y);
-                        if (t < best.t || (t == best.t && id < best.id)) {
-                            best.t = t;
-                            best.li = (int)li;
-                            best.id = id;
-                            tmax = t;
-                        }
-                    }
+        sp++;
+    }
+    __device__ __forceinline__ int pop() {
+        if (sp == 0) return kSentinel;
+        --sp;
+        return sp < lds_cap ? lds[sp * 256] : spill[(size_t)(sp - lds_cap) * spill_stride];
+    }
+};
+
+__device__ __forceinline__ void cswap(float& ka, int& ra, float& kb, int& rb) {  // order (key, ref) pairs ascending
+    const bool s = kb < ka;
+    const float k0 = s ? kb : ka, k1 = s ? ka : kb;
+    const int r0 = s ? rb : ra, r1 = s ? ra : rb;
+    ka = k0; kb = k1; ra = r0; rb = r1;
+}
+
+// One step through a 4-wide inner node (cur >= 0): fetch the 128-byte record (one L2 line), test
+// the four child boxes, continue with the nearest hit child and push the others farthest-first.
+template <bool COUNT>
+__device__ __forceinline__ void inner_step(const float4* __restrict__ nodes, const TRay& r, int& cur, TravStack& stk, TravCounters& tc) {
+    const float4* nd = nodes + (size_t)cur * 8;
+    const float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5], rf = nd[6];
+    if (COUNT) tc.nodes++;
+    float k0, k1, k2, k3;
+    const float inf = __builtin_inff();
+    k0 = box_test(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, r, k0) ? k0 : inf;
+    k1 = box_test(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, r, k1) ? k1 : inf;
+    k2 = box_test(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, r, k2) ? k2 : inf;
+    k3 = box_test(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, r, k3) ? k3 : inf;
+    int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+    // 5-comparator sorting network: nearest first, misses (key = inf) last
+    cswap(k0, r0, k1, r1);
+    cswap(k2, r2, k3, r3);
+    cswap(k0, r0, k2, r2);
+    cswap(k1, r1, k3, r3);
+    cswap(k1, r1, k2, r2);
+    if (k0 < inf) {
+        if (k3 < inf) stk.push(r3, tc.overflow);
+        if (k2 < inf) stk.push(r2, tc.overflow);
+        if (k1 < inf) stk.push(r1, tc.overflow);
+        cur = r0;
+    } else {
+        cur = stk.pop();
+    }
+}
+
+// One leaf (cur < 0, cur != sentinel): test its <= 4 triangles, then pop.  Returns true when an
+// any-hit ray found an occluder.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool leaf_step(const float4* __restrict__ tris, TRay& r, Hit& best, int& cur, TravStack& stk, TravCounters& tc) {
+    const uint32_t ref = ~(uint32_t)cur;
+    const uint32_t first = ref >> 2, cnt = (ref & 3u) + 1u;
+    // two triangles per trip: all six 16-byte loads of a pair are in flight together
+    for (uint32_t i = 0; i < cnt; i += 2) {
+        const bool two = i + 1 < cnt;
+        const float4* tp = tris + (size_t)(first + i) * 3;
+        const float4 a0 = tp[0], b0 = tp[1], c0 = tp[2];
+        float4 a1 = a0, b1 = b0, c1 = c0;
+        if (two) {
+            a1 = tp[3];
+            b1 = tp[4];
+            c1 = tp[5];
+        }
+        if (COUNT) tc.tris += two ? 2u : 1u;
+        float t0, t1;
+        const bool h0 = tri_test(r.o, r.d, mk(a0.x, a0.y, a0.z), mk(a0.w, b0.x, b0.y), mk(b0.z, b0.w, c0.x), t0) && t0 > 0.0f;
+        const bool h1 = two && tri_test(r.o, r.d, mk(a1.x, a1.y, a1.z), mk(a1.w, b1.x, b1.y), mk(b1.z, b1.w, c1.x), t1) && t1 > 0.0f;
+        if (ANY) {
+            if ((h0 && t0 < kShadowTmax) || (h1 && t1 < kShadowTmax)) return true;
+        } else {
+            if (h0) {
+                const uint32_t id = __float_as_uint(c0.y);
+                if (t0 < best.t || (t0 == best.t && id < best.id)) {
+                    best.t = t0;
+                    best.li = (int)(first + i);
+                    best.id = id;
                 }
             }
-            cur = sp ? stack[(--sp) * 256] : kSentinel;
+            if (h1) {
+                const uint32_t id = __float_as_uint(c1.y);
+                if (t1 < best.t || (t1 == best.t && id < best.id)) {
+                    best.t = t1;
+                    best.li = (int)(first + i + 1);
+                    best.id = id;
+                }
+            }
+            r.tmax = best.t;
         }
+    }
+    cur = stk.pop();
+    return false;
+}
+
+// Whole-ray traversal for one lane (used by the rt_trace_rays test hook; the render kernels drive
+// the same two step functions from a refilling persistent loop).
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris, v3 o, v3 d, TravStack& stk, Hit& best,
+                                         TravCounters& tc) {
+    TRay r = make_tray(o, d, ANY ? kShadowTmax : best.t);
+    stk.sp = 0;
+    int cur = 0;
+    while (cur != kSentinel) {
+        while (cur >= 0) inner_step<COUNT>(nodes, r, cur, stk, tc);
+        if (cur != kSentinel && leaf_step<ANY, COUNT>(tris, r, best, cur, stk, tc)) return true;
     }
     return false;
 }
@@ -196,21 +279,36 @@ __device__ __forceinline__ bool slot_pixel(const PtFrame& f, uint32_t slot, uint
     return px < f.width && py < f.height;
 }
 
-__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
-    // active-lane compaction: ballot + prefix popcount, one atomic per wave
+// Queue append with workgroup-level aggregation: ballot + prefix popcount inside each wave, the wave
+// totals meet in LDS, ONE atomic per workgroup reserves the range (a single hot counter serves only
+// ~90 atomics/us chip-wide, so one atomic per wave made the compaction kernels atomic-bound).
+// Must be called by every thread of the workgroup (two barriers inside).
+constexpr uint32_t kAppendThreads = 1024;
+__device__ __forceinline__ uint32_t block_append(bool want, uint32_t* counter, uint32_t* lds /* >= 17 words */) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const unsigned long long mask = __ballot(want);
-    uint32_t base = 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (mask) {
-        if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-        base = __shfl(base, __builtin_ctzll(mask));
+    if (lane == 0) lds[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < n_waves; w++) total += lds[w];
+        uint32_t base = total ? atomicAdd(counter, total) : 0u;
+        for (uint32_t w = 0; w < n_waves; w++) {
+            const uint32_t c = lds[w];
+            lds[w] = base;
+            base += c;
+        }
     }
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();
+    const uint32_t idx = lds[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();  // lds is reused by the next append
+    return idx;
 }
 
 // ---- generate -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pt_generate(const PtFrame f, PtState st, uint32_t* __restrict__ queue, uint32_t* __restrict__ ctr) {
-    const uint32_t pid = blockIdx.x * 256u + threadIdx.x;
+__global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, PtState st, uint32_t* __restrict__ queue, uint32_t* __restrict__ ctr) {
+    __shared__ uint32_t lds[32];
+    const uint32_t pid = blockIdx.x * kAppendThreads + threadIdx.x;
     bool alive = false;
     if (pid < f.n_paths) {
         const uint32_t slot = pid / f.spp_batch, s = f.sample0 + (pid - slot * f.spp_batch);
@@ -228,54 +326,101 @@ __global__ __launch_bounds__(256) void pt_generate(const PtFrame f, PtState st, 
         }
         st.rad[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    const uint32_t idx = wave_append(alive, &ctr[PT_CTR_COUNT]);
+    const uint32_t idx = block_append(alive, &ctr[PT_CTR_COUNT], lds);
     if (alive) queue[idx] = pid;
 }
 
 // ---- trace ----------------------------------------------------------------------------------------
-// Persistent waves: every wave pulls chunks of 64 queue entries until the queue is drained, so the
-// grid is sized for the machine, not for the (device-resident) queue length.
+// Persistent waves with per-lane refill.  Traversal lengths are heavy-tailed (a ray may end after 3
+// nodes or after 500), so a wave that waits for its slowest ray idles most lanes.  Instead every
+// lane carries its own ray: whenever at least `refill_min` lanes have finished, the wave retires
+// their results and hands them the next rays of the device-resident queue (one atomic per refill,
+// ballot + prefix-popcount to assign entries).  The wave exits when the queue is drained and all its
+// lanes are done, so the grid is sized for the machine, not for the queue length.
+// Between two refill checks every lane makes up to `kInnerPerRound` inner-node steps and one leaf step.
+constexpr int kInnerPerRound = 3;
+
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(256) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
                                                 const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
-                                                unsigned long long* __restrict__ stats) {
-    __shared__ int lds_stack[kStack * 256];
-    int* stack = &lds_stack[threadIdx.x];
+                                                unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min) {
+    extern __shared__ int lds_stack[];  // sk.lds_cap x 256 ints
+    const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
+    TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
     const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t n = *count_ptr;
-    uint32_t n_nodes = 0, n_tris = 0, overflow = 0;
+    const int inner_per_round = (int)(refill_min >> 8) ? (int)(refill_min >> 8) : kInnerPerRound;
+    refill_min &= 0xffu;
+    TravCounters tc{0, 0, 0};
+
+    TRay r = make_tray(mk(0.0f, 0.0f, 0.0f), mk(0.0f, 1.0f, 0.0f), 0.0f);
+    Hit best{0.0f, -1, 0u};
+    uint32_t slot = 0;  // closest: path id; any-hit: shadow-queue index
+    bool has_ray = false, occluded = false;
+    bool exhausted = n == 0;  // wave-uniform
+    int cur = kSentinel;
+
     for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(head, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n) break;  // wave-uniform exit: every wave reaches it once the queue is drained
-        const uint32_t i = base + lane;
-        if (i < n) {
-            if (ANY) {
-                const float4 so = st.sh_o[i], sd = st.sh_d[i];
-                Hit h{kShadowTmax, -1, 0u};
-                const bool occ = traverse<true, COUNT>(sc.nodes, sc.tris, mk(so.x, so.y, so.z), mk(sd.x, sd.y, sd.z), stack, h, n_nodes, n_tris, overflow);
-                if (!occ) {
-                    const uint32_t pid = __float_as_uint(so.w);
-                    const float4 c = st.sh_c[i];
-                    float4 L = st.rad[pid];
-                    L.x += c.x;
-                    L.y += c.y;
-                    L.z += c.z;
-                    st.rad[pid] = L;
+        const unsigned long long idle = __ballot(cur == kSentinel);
+        if (idle == ~0ull || (!exhausted && (uint32_t)__popcll(idle) >= refill_min)) {
+            if (cur == kSentinel && has_ray) {  // retire
+                if (ANY) {
+                    if (!occluded) {
+                        const uint32_t pid = __float_as_uint(st.sh_o[slot].w);
+                        const float4 c = st.sh_c[slot];
+                        float4 L = st.rad[pid];
+                        L.x += c.x;
+                        L.y += c.y;
+                        L.z += c.z;
+                        st.rad[pid] = L;
+                    }
+                } else {
+                    st.hit[slot] = make_float2(best.t, __int_as_float(best.li));
                 }
-            } else {
-                const uint32_t pid = queue[i];
-                const float4 ro = st.ray_o[pid], rd = st.ray_d[pid];
-                Hit h{__builtin_inff(), -1, 0xffffffffu};
-                traverse<false, COUNT>(sc.nodes, sc.tris, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), stack, h, n_nodes, n_tris, overflow);
-                st.hit[pid] = make_float2(h.t, __int_as_float(h.li));
+                has_ray = false;
+            }
+            if (!exhausted) {
+                const uint32_t want = (uint32_t)__popcll(idle);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, want);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (cur == kSentinel) {
+                    const uint32_t i = base + (uint32_t)__popcll(idle & lt_mask);
+                    if (i < n) {
+                        if (ANY) {
+                            const float4 so = st.sh_o[i], sd = st.sh_d[i];
+                            r = make_tray(mk(so.x, so.y, so.z), mk(sd.x, sd.y, sd.z), kShadowTmax);
+                            slot = i;
+                            occluded = false;
+                        } else {
+                            slot = queue[i];
+                            const float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
+                            r = make_tray(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), __builtin_inff());
+                            best = Hit{__builtin_inff(), -1, 0xffffffffu};
+                        }
+                        has_ray = true;
+                        cur = 0;
+                        stk.sp = 0;
+                    }
+                }
+                exhausted = base + want >= n;
+            }
+            if (__ballot(cur != kSentinel) == 0ull) break;  // queue drained and every lane retired
+        }
+#pragma unroll 1
+        for (int it = 0; it < inner_per_round; it++)
+            if (cur >= 0) inner_step<COUNT>(sc.nodes, r, cur, stk, tc);
+        if (cur < 0 && cur != kSentinel) {
+            if (leaf_step<ANY, COUNT>(sc.tris, r, best, cur, stk, tc)) {
+                occluded = true;
+                cur = kSentinel;
             }
         }
     }
     if (COUNT) {
         // wave reduction of the traversal counters, one atomic per wave
-        unsigned long long a = n_nodes, b = n_tris;
+        unsigned long long a = tc.nodes, b = tc.tris;
         for (int off = 32; off > 0; off >>= 1) {
             a += __shfl_down(a, off);
             b += __shfl_down(b, off);
@@ -285,18 +430,19 @@ __global__ __launch_bounds__(256) void pt_trace(const PtScene sc, PtState st, co
             atomicAdd(&stats[ANY ? 5 : 1], b);
         }
     }
-    if (overflow) atomicOr((unsigned int*)&stats[2], 1u);
+    if (tc.overflow) atomicOr((unsigned int*)&stats[2], 1u);
 }
 
 // ---- shade ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pt_shade(const PtScene sc, const PtFrame f, PtState st, const uint32_t* __restrict__ queue,
-                                                const uint32_t* __restrict__ count_ptr, uint32_t depth, uint32_t* __restrict__ next_queue,
-                                                uint32_t* __restrict__ next_ctr) {
+__global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, const PtFrame f, PtState st, const uint32_t* __restrict__ queue,
+                                                           const uint32_t* __restrict__ count_ptr, uint32_t depth, uint32_t* __restrict__ next_queue,
+                                                           uint32_t* __restrict__ next_ctr) {
+    __shared__ uint32_t lds[32];
     const uint32_t n = *count_ptr;
-    const uint32_t stride = gridDim.x * 256u;
-    // grid-stride over whole waves so the ballots below always see a full, converged wave
-    for (uint32_t base = blockIdx.x * 256u + (threadIdx.x & ~63u); base < n; base += stride) {
-        const uint32_t i = base + (threadIdx.x & 63u);
+    const uint32_t stride = gridDim.x * kAppendThreads;
+    // grid-stride over whole workgroups: the trip count is workgroup-uniform (barriers in block_append)
+    for (uint32_t base = blockIdx.x * kAppendThreads; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
         bool bounce = false, shadow = false;
         uint32_t pid = 0;
         float4 so = {}, sd = {}, scn = {};
@@ -366,9 +512,9 @@ __global__ __launch_bounds__(256) void pt_shade(const PtScene sc, const PtFrame 
                 }
             }
         }
-        const uint32_t bi = wave_append(bounce, &next_ctr[PT_CTR_COUNT]);
+        const uint32_t bi = block_append(bounce, &next_ctr[PT_CTR_COUNT], lds);
         if (bounce) next_queue[bi] = pid;
-        const uint32_t si = wave_append(shadow, &next_ctr[PT_CTR_SHADOW_COUNT]);
+        const uint32_t si = block_append(shadow, &next_ctr[PT_CTR_SHADOW_COUNT], lds);
         if (shadow) {
             st.sh_o[si] = so;
             st.sh_d[si] = sd;
@@ -409,43 +555,51 @@ __global__ __launch_bounds__(256) void pt_resolve(const PtFrame f, PtState st, f
 }
 
 // ---- test hook: trace a batch of caller-supplied rays ---------------------------------------------
-__global__ __launch_bounds__(256) void pt_trace_rays(const PtScene sc, const float* __restrict__ origins, const float* __restrict__ dirs, uint32_t n,
-                                                     int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out) {
-    __shared__ int lds_stack[kStack * 256];
-    int* stack = &lds_stack[threadIdx.x];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ void trace_one_ray(const PtScene& sc, const float* __restrict__ origins, const float* __restrict__ dirs, uint32_t i,
+                                              int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out, TravStack& stk) {
     const v3 o = mk(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]), d = mk(dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]);
-    uint32_t a = 0, b = 0, ov = 0;
+    TravCounters tc{0, 0, 0};
     if (any_hit) {
         Hit h{kShadowTmax, -1, 0u};
-        const bool occ = traverse<true, false>(sc.nodes, sc.tris, o, d, stack, h, a, b, ov);
+        const bool occ = traverse<true, false>(sc.nodes, sc.tris, o, d, stk, h, tc);
         t_out[i] = occ ? 1.0f : 0.0f;
         tri_out[i] = occ ? 1 : 0;
     } else {
         Hit h{__builtin_inff(), -1, 0xffffffffu};
-        traverse<false, false>(sc.nodes, sc.tris, o, d, stack, h, a, b, ov);
+        traverse<false, false>(sc.nodes, sc.tris, o, d, stk, h, tc);
         t_out[i] = h.t;
         tri_out[i] = h.li < 0 ? -1 : (int)h.id;
     }
 }
 
+__global__ __launch_bounds__(256) void pt_trace_rays(const PtScene sc, const float* __restrict__ origins, const float* __restrict__ dirs, uint32_t n,
+                                                     int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out, const StackCfg sk) {
+    extern __shared__ int lds_stack[];
+    // grid-stride so the spill columns (one per launched thread) stay within sk.spill_stride
+    const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
+    TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
+    for (uint32_t i = (uint32_t)gtid; i < n; i += gridDim.x * 256u) trace_one_ray(sc, origins, dirs, i, any_hit, t_out, tri_out, stk);
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 int launch_pt_generate(Ctx* c, const PtFrame& f, const PtState& st, uint32_t* queue, uint32_t* ctr) {
-    hipLaunchKernelGGL(pt_generate, dim3((f.n_paths + 255u) / 256u), dim3(256), 0, c->stream, f, st, queue, ctr);
+    hipLaunchKernelGGL(pt_generate, dim3((f.n_paths + kAppendThreads - 1u) / kAppendThreads), dim3(kAppendThreads), 0, c->stream, f, st, queue, ctr);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
 
 int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head,
-                    unsigned long long* stats, bool any_hit, bool count, uint32_t grid) {
+                    unsigned long long* stats, bool any_hit, bool count, uint32_t grid, const StackCfg& stack_cap, uint32_t refill_min) {
+    if (stack_cap.lds_cap < 1 || stack_cap.lds_cap > 160 || (size_t)grid * 256u > stack_cap.spill_stride)
+        return c->fail(RT_ERR_INVALID, "bad traversal stack configuration");
     const dim3 g(grid), b(256);
+    const size_t lds = (size_t)stack_cap.lds_cap * 256 * sizeof(int);
     if (any_hit) {
-        if (count) hipLaunchKernelGGL((pt_trace<true, true>), g, b, 0, c->stream, sc, st, queue, count_ptr, head, stats);
-        else hipLaunchKernelGGL((pt_trace<true, false>), g, b, 0, c->stream, sc, st, queue, count_ptr, head, stats);
+        if (count) hipLaunchKernelGGL((pt_trace<true, true>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
+        else hipLaunchKernelGGL((pt_trace<true, false>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
     } else {
-        if (count) hipLaunchKernelGGL((pt_trace<false, true>), g, b, 0, c->stream, sc, st, queue, count_ptr, head, stats);
-        else hipLaunchKernelGGL((pt_trace<false, false>), g, b, 0, c->stream, sc, st, queue, count_ptr, head, stats);
+        if (count) hipLaunchKernelGGL((pt_trace<false, true>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
+        else hipLaunchKernelGGL((pt_trace<false, false>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
     }
     RT_HIP(c, hipGetLastError());
     return RT_OK;
@@ -453,7 +607,7 @@ int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t
 
 int launch_pt_shade(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr,
                     uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid) {
-    hipLaunchKernelGGL(pt_shade, dim3(grid), dim3(256), 0, c->stream, sc, f, st, queue, count_ptr, depth, next_queue, next_ctr);
+    hipLaunchKernelGGL(pt_shade, dim3(grid), dim3(kAppendThreads), 0, c->stream, sc, f, st, queue, count_ptr, depth, next_queue, next_ctr);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -464,8 +618,11 @@ int launch_pt_resolve(Ctx* c, const PtFrame& f, const PtState& st, float* acc, f
     return RT_OK;
 }
 
-int launch_pt_trace_rays(Ctx* c, const PtScene& sc, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int* tri_out) {
-    hipLaunchKernelGGL(pt_trace_rays, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, sc, origins, dirs, n, any_hit, t_out, tri_out);
+int launch_pt_trace_rays(Ctx* c, const PtScene& sc, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int* tri_out,
+                         const StackCfg& sk, uint32_t grid) {
+    if ((size_t)grid * 256u > sk.spill_stride) return c->fail(RT_ERR_INVALID, "bad traversal stack configuration");
+    hipLaunchKernelGGL(pt_trace_rays, dim3(grid), dim3(256), (size_t)sk.lds_cap * 256 * sizeof(int), c->stream, sc, origins, dirs, n, any_hit, t_out,
+                       tri_out, sk);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -50,6 +51,8 @@ void free_mesh(PtData& pt) {
     dfree(pt.d_albedo);
     dfree(pt.d_emission);
     dfree(pt.d_lights);
+    dfree(pt.d_spill);
+    pt.spill_words = 0;
     pt.n_tris = pt.n_nodes = pt.n_lights = 0;
 }
 
@@ -77,6 +80,31 @@ int ensure_wavefront(Ctx* c, uint64_t n_paths, uint64_t n_slots) {
         pt.cap_paths = n_paths;
         pt.cap_slots = n_slots;
     }
+    return RT_OK;
+}
+
+// Traversal stack + persistent grid.  The first lds_cap entries of every lane's stack live in LDS
+// (lds_cap KiB per 256-thread workgroup), which bounds residency at floor(160 KiB / that) workgroups
+// per CU, 8 at most (32 waves per CU); the rest of the builder's worst case spills to global memory.
+int stack_config(Ctx* c, uint32_t tune_lds, uint32_t tune_blocks, rt::StackCfg* sk, uint32_t* grid) {
+    PtData& pt = c->pt;
+    const uint32_t need = std::max<uint32_t>(pt.stack_need, 1u);
+    const uint32_t lds_cap = std::min<uint32_t>(need, tune_lds ? std::min<uint32_t>(tune_lds, 160u) : 16u);
+    const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 160u / lds_cap));
+    const uint32_t blocks_per_cu = tune_blocks ? std::min<uint32_t>(tune_blocks, fit) : fit;
+    *grid = (uint32_t)c->n_cus * blocks_per_cu;
+    sk->lds_cap = (int)lds_cap;
+    sk->spill_cap = (int)(need - lds_cap);
+    sk->spill_stride = (size_t)c->n_cus * 8u * 256u;  // covers every grid this function can return
+    const size_t words = std::max<size_t>(1, (size_t)sk->spill_cap) * sk->spill_stride;
+    if (words > pt.spill_words) {
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        dfree(pt.d_spill);
+        pt.spill_words = 0;
+        if (!dalloc(pt.d_spill, words)) return c->fail(RT_ERR_OOM, "traversal spill stack (%zu words)", words);
+        pt.spill_words = words;
+    }
+    sk->spill = pt.d_spill;
     return RT_OK;
 }
 
@@ -143,9 +171,12 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
 
     const rt::PtScene sc = scene_view(pt);
     const bool count = prm->count_traversal != 0;
-    // persistent grid: enough 256-thread workgroups to fill every CU at the LDS-limited occupancy
-    const uint32_t grid_persistent = (uint32_t)c->n_cus * 5u;
-    const uint32_t grid_stride = (uint32_t)c->n_cus * 8u;
+    rt::StackCfg stack_cap{};
+    uint32_t grid_persistent = 0;
+    if (int rc = stack_config(c, prm->tune_lds_stack, prm->tune_blocks_per_cu, &stack_cap, &grid_persistent)) return rc;
+    // low byte: idle lanes that trigger a refill; next byte (tuning): inner steps per round
+    const uint32_t refill_min = (prm->tune_refill_min & 0xffu ? std::min<uint32_t>(prm->tune_refill_min & 0xffu, 64u) : 32u) | (prm->tune_refill_min & 0xff00u);
+    const uint32_t grid_stride = (uint32_t)c->n_cus * 2u;  // 1024-thread workgroups, grid-stride
 
     static thread_local std::vector<hipEvent_t> ev_pool;
     StageTimer tm{c, c->cfg.profile_stages != 0, ev_pool, {}, 0};
@@ -187,7 +218,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             const uint32_t* q = pt.d_queue[d & 1];
             uint32_t* qn = pt.d_queue[(d + 1) & 1];
             tm.begin(1);
-            if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent)) return rc;
+            if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent, stack_cap, refill_min)) return rc;
             tm.end();
             launches_closest++;
             tm.begin(2);
@@ -195,7 +226,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             tm.end();
             if (pt.n_lights) {
                 tm.begin(3);
-                if (int rc = rt::launch_pt_trace(c, sc, pt.st, nullptr, ctr_n + rt::PT_CTR_SHADOW_COUNT, ctr_n + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, true, count, grid_persistent)) return rc;
+                if (int rc = rt::launch_pt_trace(c, sc, pt.st, nullptr, ctr_n + rt::PT_CTR_SHADOW_COUNT, ctr_n + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, true, count, grid_persistent, stack_cap, refill_min)) return rc;
                 tm.end();
                 launches_shadow++;
             }
@@ -268,6 +299,9 @@ int rt_default_pt_params(rt_pt_params* p) {
     p->ray_eps = 1e-3f;
     p->count_traversal = 0;
     p->max_paths = 0;
+    p->tune_refill_min = 0;
+    p->tune_blocks_per_cu = 0;
+    p->tune_lds_stack = 0;
     return RT_OK;
 }
 
@@ -294,6 +328,7 @@ int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const floa
         }
     const auto t0 = std::chrono::steady_clock::now();
     rt::BvhResult bvh;
+    if (const char* lf = std::getenv("RT_BVH_LEAF")) bvh.leaf_max = (uint32_t)std::atoi(lf);  // tuning knob
     if (!rt::build_bvh(v0.data(), e1.data(), e2.data(), n_tris, rt::kBvhMaxDepth, &bvh)) return c->fail(RT_ERR_INVALID, "BVH build failed");
     pt.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
@@ -319,13 +354,13 @@ int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const floa
     for (size_t t = 0; t < n; t++)
         if (emission[3 * t] > 0.0f || emission[3 * t + 1] > 0.0f || emission[3 * t + 2] > 0.0f) lights.push_back(leaf_pos[t]);
 
-    const bool ok = dalloc(pt.d_nodes, (size_t)bvh.n_nodes * 4) && dalloc(pt.d_tris, n * 3) && dalloc(pt.d_albedo, n) && dalloc(pt.d_emission, n) &&
+    const bool ok = dalloc(pt.d_nodes, (size_t)bvh.n_nodes * 8) && dalloc(pt.d_tris, n * 3) && dalloc(pt.d_albedo, n) && dalloc(pt.d_emission, n) &&
                     dalloc(pt.d_lights, std::max<size_t>(lights.size(), 1));
     if (!ok) {
         free_mesh(pt);
         return c->fail(RT_ERR_OOM, "mesh of %u triangles", n_tris);
     }
-    RT_HIP(c, hipMemcpy(pt.d_nodes, bvh.nodes.data(), (size_t)bvh.n_nodes * 64, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(pt.d_nodes, bvh.nodes.data(), (size_t)bvh.n_nodes * 128, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(pt.d_tris, tris.data(), n * 48, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(pt.d_albedo, alb.data(), n * 16, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(pt.d_emission, emi.data(), n * 16, hipMemcpyHostToDevice));
@@ -334,11 +369,13 @@ int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const floa
     pt.n_nodes = bvh.n_nodes;
     pt.n_lights = (uint32_t)lights.size();
     pt.bvh_depth = bvh.depth;
+    pt.stack_need = bvh.stack_need;
     pt.bvh_pad = bvh.pad;
     pt.stats = rt_pt_stats{};
     pt.stats.n_tris = n_tris;
     pt.stats.n_nodes = bvh.n_nodes;
     pt.stats.bvh_depth = bvh.depth;
+    pt.stats.stack_need = bvh.stack_need;
     pt.stats.n_lights = pt.n_lights;
     pt.stats.bvh_build_ms = pt.bvh_build_ms;
     return RT_OK;
@@ -384,7 +421,10 @@ int rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t
     hipError_t e = hipSuccess;
     if (!rc) e = hipMemcpy(d_o, origins, nb * 12, hipMemcpyHostToDevice);
     if (!rc && e == hipSuccess) e = hipMemcpy(d_d, dirs, nb * 12, hipMemcpyHostToDevice);
-    if (!rc && e == hipSuccess) rc = rt::launch_pt_trace_rays(c, scene_view(c->pt), d_o, d_d, n, any_hit, d_t, d_i);
+    rt::StackCfg sk{};
+    uint32_t grid = 0;
+    if (!rc) rc = stack_config(c, 0, 0, &sk, &grid);
+    if (!rc && e == hipSuccess) rc = rt::launch_pt_trace_rays(c, scene_view(c->pt), d_o, d_d, n, any_hit, d_t, d_i, sk, std::min<uint32_t>(grid, (n + 255u) / 256u));
     if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (!rc && e == hipSuccess) e = hipMemcpy(t_out, d_t, nb * 4, hipMemcpyDeviceToHost);
     if (!rc && e == hipSuccess) e = hipMemcpy(tri_out, d_i, nb * 4, hipMemcpyDeviceToHost);

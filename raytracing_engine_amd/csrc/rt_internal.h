@@ -88,6 +88,12 @@ struct PtScene {
     uint32_t n_tris;
 };
 
+struct StackCfg {  // per-lane traversal stack: lds_cap entries in LDS, then spill_cap entries in global memory
+    int* spill;           // spill_cap x spill_stride ints, entry-major
+    size_t spill_stride;  // = threads of the persistent grid
+    int lds_cap, spill_cap;
+};
+
 struct PtState {  // SoA over path ids; one float4 per lane per array = 16-byte coalesced accesses
     float4* ray_o;
     float4* ray_d;
@@ -122,6 +128,9 @@ struct PtData {  // device residency of one mesh + the wavefront buffers
     float4* d_albedo = nullptr;
     float4* d_emission = nullptr;
     uint32_t* d_lights = nullptr;
+    uint32_t stack_need = 0;  // worst-case traversal stack occupancy reported by the builder
+    int* d_spill = nullptr;
+    size_t spill_words = 0;
     // wavefront buffers, sized for cap_paths
     uint64_t cap_paths = 0;
     uint32_t cap_depth = 0;
@@ -188,12 +197,12 @@ int launch_to_rgba8(Ctx* c, const float* rgb, uint8_t* rgba, uint64_t n_pixels);
 // path_b.hip
 int launch_pt_generate(Ctx* c, const PtFrame& f, const PtState& st, uint32_t* queue, uint32_t* ctr);
 int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head,
-                    unsigned long long* stats, bool any_hit, bool count, uint32_t grid);
+                    unsigned long long* stats, bool any_hit, bool count, uint32_t grid, const StackCfg& stack_cap, uint32_t refill_min);
 int launch_pt_shade(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr,
                     uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid);
 int launch_pt_resolve(Ctx* c, const PtFrame& f, const PtState& st, float* acc, float* dst, int tile_major);
 int launch_pt_trace_rays(Ctx* c, const PtScene& sc, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out,
-                         int* tri_out);
+                         int* tri_out, const StackCfg& sk, uint32_t grid);
 void pt_free(Ctx* c);
 
 }  // namespace rt
