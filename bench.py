@@ -257,7 +257,7 @@ def main():
             wl.step(frame.data_ptr(), False)
         else:
             wl.step(mine.data_ptr(), True)
-            dist.gather(mine, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            R.host.gather_tiles(mine, gathered, rank, dist)
             if rank == 0:
                 r.detile_device(gathered.data_ptr(), world, tiles_per_rank, frame.data_ptr())
 

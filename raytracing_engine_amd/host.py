@@ -298,3 +298,24 @@ def tiles_to_frame(tiles, n_ranks, tiles_per_rank, width, height):
         y, x = divmod(t, tx)
         out[y * T:(y + 1) * T, x * T:(x + 1) * T] = tiles[r * tiles_per_rank + k]
     return out[:height, :width]
+
+
+def frame_to_tiles(frame, rank, n_ranks, tiles_per_rank):
+    """numpy model of the tile-major output of rt_render*_device(tile_major=1): the tiles owned by
+    `rank` (tile t -> rank t % n_ranks), zero-padded to tiles_per_rank x 64 x 64 x 3."""
+    T = _lib.RT_TILE
+    h, w = frame.shape[:2]
+    tx, ty = -(-w // T), -(-h // T)
+    out = np.zeros((tiles_per_rank, T, T, 3), frame.dtype)
+    for k, t in enumerate(range(rank, tx * ty, n_ranks)):
+        y, x = divmod(t, tx)
+        blk = frame[y * T:(y + 1) * T, x * T:(x + 1) * T]
+        out[k, :blk.shape[0], :blk.shape[1]] = blk
+    return out
+
+
+def gather_tiles(mine, gathered, rank, dist):
+    """The one exchange step of a multi-GPU frame: every rank's tile-major buffer goes
+    to rank 0 (torch.distributed gather; backend nccl = RCCL over xGMI on GPUs, gloo in the CPU tests).
+    `gathered` is a (world, tiles_per_rank, 64, 64, 3) tensor on rank 0, None elsewhere."""
+    dist.gather(mine, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
