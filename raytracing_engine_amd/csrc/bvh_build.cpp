@@ -5,18 +5,11 @@
 // (boxes are padded conservatively, closest hit = lexicographic (t, triangle id) minimum), so the
 // builder is free to optimise for traversal cost only.
 //
-// The binary SAH tree is collapsed into a 4-wide BVH: traversal on gfx950 is bound by the latency of
-// dependent node fetches (L2 / Infinity-Cache round trips), so halving the number of levels matters
-// more than the extra box tests per step.
-//
-// Output layout, sized for per-lane gathers on gfx950:
-//   nodes: one 128-byte record (= one L2 line) per inner node = 8 x float4, children planar (SoA):
-//       q0 = lo.x[0..3]  q1 = lo.y[0..3]  q2 = lo.z[0..3]  q3 = hi.x[0..3]  q4 = hi.y[0..3]  q5 = hi.z[0..3]
-//       q6 = ref[0..3]   q7 = unused
-//       ref >= 0: inner node index; ref < 0: leaf, ~ref = (first << 2) | (count - 1), count <= 4;
-//       ref == 0x80000000: empty slot (its box is a far-away point no ray reaches)
-//   order: leaf-order position -> original triangle index (triangle records are stored in leaf order
-//       so a leaf's triangles are contiguous)
+// The binary SAH tree is collapsed into a compressed 8-wide BVH (after Ylitie, Karras, Laine,
+// "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017): traversal on
+// gfx950 is bound by the vector L1's request rate (one lane-address per cycle; a divergent 16-byte
+// load is 64 of them), so the node format minimises 16-byte fetches per ray: 8 children in 5 fetches.
+// Layout: bvh_build.h.
 #include "bvh_build.h"
 
 #include <algorithm>
@@ -197,59 +190,266 @@ struct Builder {
 
 namespace {
 
-constexpr int32_t kEmptyRef = (int32_t)0x80000000;
-
 struct Child {
     float box[6];  // lo.xyz, hi.xyz (already padded)
-    int32_t ref;   // BVH2 ref
-    float area() const {
-        const float dx = box[3] - box[0], dy = box[4] - box[1], dz = box[5] - box[2];
-        return dx * dy + dy * dz + dz * dx;
-    }
+    int32_t ref;   // >= 0: binary inner node that becomes an 8-wide node; < 0: leaf ~((first << 2) | (count - 1)), count <= 3
 };
 
-struct Collapser {
-    const std::vector<float>& n2;  // 16 floats per binary node
-    std::vector<float>& n4;        // 32 floats per 4-wide node
-    uint32_t stack_need = 0, depth = 0;
+inline float box_area(const float b[6]) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
 
-    void children_of(int32_t node2, Child out[2]) const {
-        const float* n = &n2[(size_t)node2 * 16];
-        std::memcpy(out[0].box, n, 24);
-        std::memcpy(out[1].box, n + 6, 24);
-        std::memcpy(&out[0].ref, n + 12, 4);
-        std::memcpy(&out[1].ref, n + 13, 4);
+// Binary SAH tree (one triangle per leaf) -> compressed 8-wide BVH (layout in bvh_build.h).
+// Which binary nodes become 8-wide nodes, which subtrees become <= 3-triangle leaves and how the 8
+// child slots of every node are spent is chosen by the dynamic program of Ylitie et al. 2017 (§4.1):
+//   C(n,1)   = min( A(n) P(n) c_prim  [P(n) <= 3],   A(n) c_node + D(n,8) )
+//   C(n,i>1) = min( D(n,i), C(n,i-1) ),   D(n,i) = min_{0<k<i} C(left,k) + C(right,i-k)
+// Nodes are emitted breadth-first so that the inner children of a node are consecutive
+// (child_base + rank among inner slots) and the triangles of its leaf children are consecutive
+// (tri_base + offset < 24).
+struct Cw8Builder {
+    const std::vector<float>& n2;           // 16 floats per binary node
+    const std::vector<uint32_t>& order2;    // binary leaf order -> triangle id
+    std::vector<uint32_t>& nodes;           // 20 words per node
+    std::vector<uint32_t>& order8;          // final leaf order -> triangle id
+    uint32_t depth = 0;
+
+    static constexpr float kCostNode = 1.0f, kCostPrim = 0.3f;
+    struct Dp {
+        float cost[8];     // cost[i], i = 1..7: subtree as a forest of <= i roots
+        uint8_t split[9];  // split[i], i = 2..8: roots given to the left child in D(n,i)
+        uint8_t prev;      // bit i set: C(n,i) = C(n,i-1)
+        uint8_t is_leaf;   // C(n,1) chose the leaf
+        uint32_t first, prims;
+        float box[6];
+    };
+    std::vector<Dp> dp;
+
+    void child_box(int32_t node2, int side, float out[6]) const { std::memcpy(out, &n2[(size_t)node2 * 16 + 6 * side], 24); }
+    int32_t child_ref(int32_t node2, int side) const {
+        int32_t r;
+        std::memcpy(&r, &n2[(size_t)node2 * 16 + 12 + side], 4);
+        return r;
     }
 
-    // below = stack entries already held when this node is entered (worst case)
-    int32_t collapse(int32_t node2, uint32_t below, uint32_t level) {
-        Child ch[4];
-        int k = 2;
-        children_of(node2, ch);
-        if (ch[0].ref < 0 && ch[0].ref == ch[1].ref) k = 1;  // tiny mesh: both binary slots name one leaf
-        while (k < 4) {  // open the inner child with the largest surface until 4 children
-            int best = -1;
-            for (int i = 0; i < k; i++)
-                if (ch[i].ref >= 0 && (best < 0 || ch[i].area() > ch[best].area())) best = i;
-            if (best < 0) break;
-            Child two[2];
-            children_of(ch[best].ref, two);
-            ch[best] = two[0];
-            ch[k++] = two[1];
+    void solve() {
+        const size_t n_nodes = n2.size() / 16;
+        dp.resize(n_nodes);
+        for (size_t jj = n_nodes; jj-- > 0;) {  // children have larger indices than their parent
+            const int32_t j = (int32_t)jj;
+            Dp& d = dp[jj];
+            float cb[2][6], carea[2];
+            int32_t cr[2];
+            uint32_t cprims[2], cfirst[2];
+            for (int s = 0; s < 2; s++) {
+                child_box(j, s, cb[s]);
+                cr[s] = child_ref(j, s);
+                carea[s] = box_area(cb[s]);
+                if (cr[s] < 0) {
+                    const uint32_t ref = ~(uint32_t)cr[s];
+                    cfirst[s] = ref >> 2;
+                    cprims[s] = (ref & 3u) + 1u;
+                } else {
+                    cfirst[s] = dp[cr[s]].first;
+                    cprims[s] = dp[cr[s]].prims;
+                }
+            }
+            auto C = [&](int s, int i) -> float {
+                if (cr[s] < 0) return carea[s] * (float)cprims[s] * kCostPrim;
+                return dp[cr[s]].cost[i > 7 ? 7 : i];
+            };
+            for (int a = 0; a < 3; a++) {
+                d.box[a] = std::min(cb[0][a], cb[1][a]);
+                d.box[3 + a] = std::max(cb[0][3 + a], cb[1][3 + a]);
+            }
+            const bool same = cr[0] < 0 && cr[0] == cr[1];  // tiny mesh: both slots name one leaf
+            d.first = std::min(cfirst[0], cfirst[1]);
+            d.prims = same ? cprims[0] : cprims[0] + cprims[1];
+            float D[9];
+            D[1] = std::numeric_limits<float>::infinity();
+            for (int i = 2; i <= 8; i++) {
+                float best = std::numeric_limits<float>::infinity();
+                int bk = 1;
+                for (int k = 1; k < i; k++) {
+                    const float c = C(0, k) + C(1, i - k);
+                    if (c < best) {
+                        best = c;
+                        bk = k;
+                    }
+                }
+                D[i] = best;
+                d.split[i] = (uint8_t)bk;
+            }
+            const float area = box_area(d.box);
+            const float c_leaf = d.prims <= 3 ? area * (float)d.prims * kCostPrim : std::numeric_limits<float>::infinity();
+            const float c_int = D[8] + area * kCostNode;
+            d.is_leaf = c_leaf <= c_int;
+            d.cost[1] = d.is_leaf ? c_leaf : c_int;
+            d.prev = 0;
+            for (int i = 2; i <= 7; i++) {
+                if (d.cost[i - 1] <= D[i]) {
+                    d.cost[i] = d.cost[i - 1];
+                    d.prev |= (uint8_t)(1u << i);
+                } else {
+                    d.cost[i] = D[i];
+                }
+            }
+            d.cost[0] = 0.0f;
         }
-        const uint32_t me = (uint32_t)(n4.size() / 32);
-        n4.resize(n4.size() + 32);
-        const uint32_t held = below + (uint32_t)(k - 1);
-        stack_need = std::max(stack_need, held);
-        depth = std::max(depth, level + 1);
-        int32_t refs[4];
-        for (int i = 0; i < 4; i++) refs[i] = i < k ? (ch[i].ref < 0 ? ch[i].ref : collapse(ch[i].ref, held, level + 1)) : kEmptyRef;
-        float* n = &n4[(size_t)me * 32];
-        for (int i = 0; i < 4; i++)
-            for (int a = 0; a < 6; a++) n[a * 4 + i] = i < k ? ch[i].box[a] : 3.0e38f;
-        std::memcpy(n + 24, refs, 16);
-        n[28] = n[29] = n[30] = n[31] = 0.0f;
-        return (int32_t)me;
+    }
+
+    // represent binary subtree `ref` (box `box`) as a forest of at most `budget` roots
+    void expand(int32_t ref, const float box[6], int budget, Child* out, int& k) const {
+        if (ref < 0) {
+            std::memcpy(out[k].box, box, 24);
+            out[k++].ref = ref;
+            return;
+        }
+        const Dp& d = dp[ref];
+        if (budget > 7) budget = 7;
+        while (budget > 1 && ((d.prev >> budget) & 1)) budget--;
+        if (budget == 1) {
+            std::memcpy(out[k].box, d.box, 24);
+            out[k++].ref = d.is_leaf ? ~(int32_t)((d.first << 2) | (d.prims - 1u)) : ref;
+            return;
+        }
+        distribute(ref, budget, out, k);
+    }
+    void distribute(int32_t node2, int budget, Child* out, int& k) const {
+        const int kl = dp[node2].split[budget];
+        float b0[6], b1[6];
+        child_box(node2, 0, b0);
+        child_box(node2, 1, b1);
+        const int32_t r0 = child_ref(node2, 0), r1 = child_ref(node2, 1);
+        if (r0 < 0 && r0 == r1) {  // tiny mesh
+            expand(r0, b0, 1, out, k);
+            return;
+        }
+        expand(r0, b0, kl, out, k);
+        expand(r1, b1, budget - kl, out, k);
+    }
+
+    struct Pending {
+        int32_t node2;
+        uint32_t index, level;
+    };
+
+    void emit(const Pending& pd, std::vector<Pending>& queue) {
+        Child ch[8];
+        int k = 0;
+        if (dp[pd.node2].is_leaf && pd.level == 0) {  // whole mesh fits one leaf: root node with a single leaf child
+            const Dp& d = dp[pd.node2];
+            std::memcpy(ch[0].box, d.box, 24);
+            ch[0].ref = ~(int32_t)((d.first << 2) | (d.prims - 1u));
+            k = 1;
+        } else {
+            distribute(pd.node2, 8, ch, k);
+        }
+        depth = std::max(depth, pd.level + 1);
+
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {
+            lo[a] = ch[0].box[a];
+            hi[a] = ch[0].box[3 + a];
+            for (int i = 1; i < k; i++) {
+                lo[a] = std::min(lo[a], ch[i].box[a]);
+                hi[a] = std::max(hi[a], ch[i].box[3 + a]);
+            }
+        }
+        // slot assignment: slot bits (x,y,z) = which side of the node centre the child sits on, so that
+        // slot ^ (7 - ray octant) orders children front to back; greedy on dot(child centre - node centre, slot dir)
+        int slot_of[8], child_in[8];
+        for (int i = 0; i < 8; i++) slot_of[i] = child_in[i] = -1;
+        for (int round = 0; round < k; round++) {
+            float best = -std::numeric_limits<float>::infinity();
+            int bi = -1, bs = -1;
+            for (int i = 0; i < k; i++) {
+                if (slot_of[i] >= 0) continue;
+                for (int s = 0; s < 8; s++) {
+                    if (child_in[s] >= 0) continue;
+                    float c = 0.0f;
+                    for (int a = 0; a < 3; a++) {
+                        const float off = 0.5f * (ch[i].box[a] + ch[i].box[3 + a]) - 0.5f * (lo[a] + hi[a]);
+                        c += ((s >> (2 - a)) & 1) ? off : -off;
+                    }
+                    if (c > best) {
+                        best = c;
+                        bi = i;
+                        bs = s;
+                    }
+                }
+            }
+            slot_of[bi] = bs;
+            child_in[bs] = bi;
+        }
+
+        // quantisation frame: p = lo, per-axis power-of-two scale with 255 * scale >= extent
+        uint32_t e_byte[3];
+        double scale[3];
+        for (int a = 0; a < 3; a++) {
+            const double ext = (double)hi[a] - (double)lo[a];
+            int e = ext > 0.0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
+            e = std::min(std::max(e, -126), 127);
+            while (e < 127 && std::ldexp(255.0, e) < ext) e++;
+            e_byte[a] = (uint32_t)(e + 127);
+            scale[a] = std::ldexp(1.0, e);
+        }
+
+        uint32_t* w = &nodes[(size_t)pd.index * 20];
+        std::memcpy(w, lo, 12);
+        uint32_t imask = 0, n_inner = 0;
+        for (int s = 0; s < 8; s++)
+            if (child_in[s] >= 0 && ch[child_in[s]].ref >= 0) {
+                imask |= 1u << s;
+                n_inner++;
+            }
+        w[3] = e_byte[0] | (e_byte[1] << 8) | (e_byte[2] << 16) | (imask << 24);
+        const uint32_t child_base = (uint32_t)(nodes.size() / 20);
+        const uint32_t tri_base = (uint32_t)order8.size();
+        w[4] = child_base;
+        w[5] = tri_base;
+        nodes.resize(nodes.size() + (size_t)n_inner * 20);
+        w = &nodes[(size_t)pd.index * 20];  // resize may have moved the storage
+        uint8_t meta[8] = {}, q[6][8];
+        for (int a = 0; a < 6; a++)
+            for (int s = 0; s < 8; s++) q[a][s] = a < 3 ? 255 : 0;  // empty slot: inverted box, meta 0
+        uint32_t rank = 0;
+        for (int s = 0; s < 8; s++) {
+            const int i = child_in[s];
+            if (i < 0) continue;
+            if (ch[i].ref >= 0) {
+                meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
+                queue.push_back(Pending{ch[i].ref, child_base + rank, pd.level + 1});
+                rank++;
+            } else {
+                const uint32_t ref = ~(uint32_t)ch[i].ref, first = ref >> 2, cnt = (ref & 3u) + 1u;  // cnt <= 3
+                const uint32_t off = (uint32_t)order8.size() - tri_base;
+                meta[s] = (uint8_t)((((1u << cnt) - 1u) << 5) | off);
+                for (uint32_t t = 0; t < cnt; t++) order8.push_back(order2[first + t]);
+            }
+            for (int a = 0; a < 3; a++) {
+                double ql = std::floor(((double)ch[i].box[a] - (double)lo[a]) / scale[a]);
+                double qh = std::ceil(((double)ch[i].box[3 + a] - (double)lo[a]) / scale[a]);
+                ql = std::min(std::max(ql, 0.0), 255.0);
+                qh = std::min(std::max(qh, 0.0), 255.0);
+                q[a][s] = (uint8_t)ql;
+                q[3 + a][s] = (uint8_t)qh;
+            }
+        }
+        std::memcpy(&w[6], meta, 8);
+        for (int a = 0; a < 6; a++) std::memcpy(&w[8 + 2 * a], q[a], 8);
+    }
+
+    void build() {
+        solve();
+        nodes.assign(20, 0u);
+        std::vector<Pending> queue;
+        queue.push_back(Pending{0, 0, 0});
+        for (size_t head = 0; head < queue.size(); head++) {
+            const Pending pd = queue[head];
+            emit(pd, queue);
+        }
     }
 };
 
@@ -278,17 +478,17 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
     }
     out->order.resize(n);
     for (uint32_t i = 0; i < n; i++) out->order[i] = i;
-    out->nodes.clear();
-    out->nodes.reserve(16 * (size_t)(n / 2 + 16));
+    std::vector<float> binary;
+    binary.reserve(16 * (size_t)(n / 2 + 16));
     // conservative padding: absorbs the rounding of the slab test and of Moeller-Trumbore's t
     out->pad = 2e-5f * std::max(maxabs, 1.0f);
-    const uint32_t leaf_max = std::min<uint32_t>(std::max<uint32_t>(out->leaf_max, 1u), 4u);
-    Builder b{tri_box, centroid, out->order, out->nodes, out->pad, max_depth, leaf_max};
+    const uint32_t leaf_max = 1;  // the binary tree goes down to single triangles; the collapse forms the <= 3-triangle leaves
+    Builder b{tri_box, centroid, out->order, binary, out->pad, max_depth, leaf_max};
     if (n <= leaf_max) {
         // one node whose two slots name the same leaf (testing it twice is idempotent)
-        out->nodes.resize(16);
+        binary.resize(16);
         Box bx = b.range_box(0, n);
-        float* nd = out->nodes.data();
+        float* nd = binary.data();
         const float p = out->pad;
         const float box[6] = {bx.lo[0] - p, bx.lo[1] - p, bx.lo[2] - p, bx.hi[0] + p, bx.hi[1] + p, bx.hi[2] + p};
         std::memcpy(nd, box, 24);
@@ -303,15 +503,16 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
         out->depth = b.depth_reached + 1;
     }
     out->sah_area = b.sah;
-    // collapse to 4-wide nodes
-    std::vector<float> binary;
-    binary.swap(out->nodes);
-    out->nodes.reserve(binary.size());
-    Collapser col{binary, out->nodes};
-    col.collapse(0, 0, 0);
-    out->n_nodes = (uint32_t)(out->nodes.size() / 32);
-    out->depth = col.depth;
-    out->stack_need = col.stack_need;
+    // collapse to compressed 8-wide nodes; triangles are re-ordered so every node's leaf triangles are contiguous
+    std::vector<uint32_t> order2;
+    order2.swap(out->order);
+    out->order.reserve(n);
+    Cw8Builder cw{binary, order2, out->nodes, out->order, 0, {}};
+    cw.build();
+    if (out->order.size() != n) return false;
+    out->n_nodes = (uint32_t)(out->nodes.size() / 20);
+    out->depth = cw.depth;
+    out->stack_need = cw.depth + 1;  // at most one pending sibling group per level
     return true;
 }
 

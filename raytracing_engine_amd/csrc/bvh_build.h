@@ -1,4 +1,17 @@
-// bvh_build.h — host BVH2 builder for path B (see bvh_build.cpp for the layout).
+// bvh_build.h — host BVH builder for path B: binned-SAH binary tree -> compressed 8-wide nodes.
+//
+// Node = 80 bytes = 5 x 16-byte fetches for 8 children (20 little-endian words):
+//   w0..w2  p.xyz (f32)        origin of the node's quantisation frame (= box minimum)
+//   w3      ex | ey<<8 | ez<<16 | imask<<24    per-axis scale = 2^(e-127) as a float exponent byte;
+//                                               imask bit s = child slot s is an inner node
+//   w4      child_base         index of the first inner child; inner child in slot s lives at
+//                              child_base + popcount(imask & ((1<<s)-1))
+//   w5      tri_base           leaf-order index of the node's first leaf triangle
+//   w6..w7  meta[8]            per slot: 0 empty; inner: 001sssss with sssss = 24 + slot;
+//                              leaf: (unary triangle count 001/011/111) << 5 | offset from tri_base (< 24)
+//   w8..w19 qlo.x[8] qlo.y[8] qlo.z[8] qhi.x[8] qhi.y[8] qhi.z[8]   child boxes, 8 bits per plane,
+//                              box = p + q * scale, rounded outward (conservative)
+// Child slots are assigned so that slot ^ (7 - ray octant) enumerates children roughly front to back.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -6,11 +19,10 @@
 namespace rt {
 
 struct BvhResult {
-    std::vector<float> nodes;     // 32 floats (128 B) per 4-wide node
+    std::vector<uint32_t> nodes;  // 20 words (80 B) per compressed 8-wide node
     std::vector<uint32_t> order;  // leaf-order position -> original triangle index
-    uint32_t leaf_max = 2;        // in: triangles per leaf (1..4); 2 measured best on the bench scene
     uint32_t n_nodes = 0;
-    uint32_t depth = 0;           // levels of 4-wide inner nodes (root = 1)
+    uint32_t depth = 0;           // levels of 8-wide inner nodes (root = 1)
     uint32_t stack_need = 0;      // worst-case traversal stack occupancy (entries)
     float pad = 0.0f;             // conservative box padding that was applied
     double sah_area = 0.0;        // sum of child half-areas (quality metric)

@@ -23,7 +23,6 @@
 namespace rt {
 using namespace rtk;
 
-constexpr int kSentinel = (int)0x80000000;
 constexpr float kShadowTmax = 0.999f;
 
 // ---- spec §6.2: counter-based RNG -------------------------------------------------------------
@@ -95,12 +94,13 @@ __device__ __forceinline__ v3 safe_inv(v3 d) {
     return mk(1.0f / x, 1.0f / y, 1.0f / z);
 }
 
-// A ray in traversal form.  The slab test uses t = lo*inv - o*inv (one fma per plane); boxes are
-// padded at build time, so this test only has to be conservative, not bit-identical to anything
-// (results do not depend on which boxes are visited).
+// A ray in traversal form.  The slab test uses t = plane*inv - o*inv (one fma per plane); boxes are
+// padded at build time and quantised outward, so this test only has to be conservative, not
+// bit-identical to anything (results do not depend on which boxes are visited).
 struct TRay {
     v3 o, d, inv, noi;  // noi = -(o * inv)
     float tmax;
+    uint32_t oct_inv;   // 7 - octant: slot ^ oct_inv enumerates a node's children front to back
 };
 __device__ __forceinline__ TRay make_tray(v3 o, v3 d, float tmax) {
     TRay r;
@@ -109,16 +109,8 @@ __device__ __forceinline__ TRay make_tray(v3 o, v3 d, float tmax) {
     r.inv = safe_inv(d);
     r.noi = mk(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
     r.tmax = tmax;
+    r.oct_inv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
     return r;
-}
-
-__device__ __forceinline__ bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, const TRay& r, float& tn) {
-    const float t0x = __builtin_fmaf(lox, r.inv.x, r.noi.x), t1x = __builtin_fmaf(hix, r.inv.x, r.noi.x);
-    const float t0y = __builtin_fmaf(loy, r.inv.y, r.noi.y), t1y = __builtin_fmaf(hiy, r.inv.y, r.noi.y);
-    const float t0z = __builtin_fmaf(loz, r.inv.z, r.noi.z), t1z = __builtin_fmaf(hiz, r.inv.z, r.noi.z);
-    tn = fmax_(fmax_(fmin_(t0x, t1x), fmin_(t0y, t1y)), fmax_(fmin_(t0z, t1z), 0.0f));
-    const float tf = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), r.tmax));
-    return tn <= tf * 1.0000004f;
 }
 
 struct Hit {
@@ -131,17 +123,26 @@ struct TravCounters {
     uint32_t nodes, tris, overflow;
 };
 
-// Per-lane traversal stack.  The first `lds_cap` entries live in LDS (column of this thread, stride
-// 256 ints: bank = lane, conflict-free); deeper entries - rare, the worst case of a 4-wide tree is
-// 3 entries per level - spill to a global column (entry-major, so a wave's spill is coalesced).
-// The builder reports the exact worst-case occupancy and the host sizes lds_cap + spill_cap to it.
+// A traversal work item (Ylitie et al. 2017): either a node group  x = child_base,
+// y = hit bits of inner children in 31..24 | the parent's imask in 7..0;  or a triangle group
+// x = tri_base, y = hit bits of leaf triangles in 23..0.
+struct Group {
+    uint32_t x, y;
+};
+__device__ __forceinline__ bool has_nodes(const Group& g) { return g.y > 0x00ffffffu; }
+
+// Per-lane traversal stack of 8-byte groups.  The first `lds_cap` entries live in LDS (column of
+// this thread, stride 256 entries: conflict-free); the tree pushes at most one pending sibling
+// group per level, the builder reports the depth and the host sizes lds_cap + spill_cap to it;
+// entries beyond lds_cap spill to a global column (entry-major, coalesced across a wave).
 struct TravStack {
-    int* lds;
-    int* spill;
+    unsigned long long* lds;
+    unsigned long long* spill;
     size_t spill_stride;
     int lds_cap, spill_cap;
     int sp;
-    __device__ __forceinline__ void push(int v, uint32_t& overflow) {
+    __device__ __forceinline__ void push(Group g, uint32_t& overflow) {
+        const unsigned long long v = ((unsigned long long)g.y << 32) | g.x;
         if (sp < lds_cap) lds[sp * 256] = v;
         else if (sp - lds_cap < spill_cap) spill[(size_t)(sp - lds_cap) * spill_stride] = v;
         else {
@@ -150,110 +151,118 @@ struct TravStack {
         }
         sp++;
     }
-    __device__ __forceinline__ int pop() {
-        if (sp == 0) return kSentinel;
+    __device__ __forceinline__ Group pop() {  // caller checks sp > 0
         --sp;
-        return sp < lds_cap ? lds[sp * 256] : spill[(size_t)(sp - lds_cap) * spill_stride];
+        const unsigned long long v = sp < lds_cap ? lds[sp * 256] : spill[(size_t)(sp - lds_cap) * spill_stride];
+        return Group{(uint32_t)v, (uint32_t)(v >> 32)};
     }
 };
 
-__device__ __forceinline__ void cswap(float& ka, int& ra, float& kb, int& rb) {  // order (key, ref) pairs ascending
-    const bool s = kb < ka;
-    const float k0 = s ? kb : ka, k1 = s ? ka : kb;
-    const int r0 = s ? rb : ra, r1 = s ? ra : rb;
-    ka = k0; kb = k1; ra = r0; rb = r1;
+__device__ __forceinline__ float ubyte_f32(uint32_t w, int byte) {  // v_cvt_f32_ubyteN
+    return (float)((w >> (8 * byte)) & 0xffu);
 }
 
-// One step through a 4-wide inner node (cur >= 0): fetch the 128-byte record (one L2 line), test
-// the four child boxes, continue with the nearest hit child and push the others farthest-first.
+// Visit the nearest pending inner child of node group G: fetch its 80-byte record (five 16-byte
+// loads for eight children), slab-test the eight quantised boxes and turn the hits into a new node
+// group (inner children, ordered by ray octant) and a triangle group (leaf triangles).
 template <bool COUNT>
-__device__ __forceinline__ void inner_step(const float4* __restrict__ nodes, const TRay& r, int& cur, TravStack& stk, TravCounters& tc) {
-    const float4* nd = nodes + (size_t)cur * 8;
-    const float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5], rf = nd[6];
+__device__ __forceinline__ void node_step(const float4* __restrict__ nodes, const TRay& r, Group& G, Group& T, TravStack& stk, TravCounters& tc) {
+    const uint32_t hits = G.y;
+    const uint32_t bit = 31u - (uint32_t)__builtin_clz(hits);
+    G.y &= ~(1u << bit);
+    if (has_nodes(G)) stk.push(G, tc.overflow);  // remaining siblings
+    const uint32_t slot = (bit - 24u) ^ r.oct_inv;
+    const uint32_t rel = (uint32_t)__builtin_popcount(hits & ~(0xffffffffu << slot));  // low byte of hits = imask
+    const float4* nd = nodes + (size_t)(G.x + rel) * 5;
+    const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[4];
     if (COUNT) tc.nodes++;
-    float k0, k1, k2, k3;
-    const float inf = __builtin_inff();
-    k0 = box_test(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, r, k0) ? k0 : inf;
-    k1 = box_test(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, r, k1) ? k1 : inf;
-    k2 = box_test(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, r, k2) ? k2 : inf;
-    k3 = box_test(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, r, k3) ? k3 : inf;
-    int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
-    // 5-comparator sorting network: nearest first, misses (key = inf) last
-    cswap(k0, r0, k1, r1);
-    cswap(k2, r2, k3, r3);
-    cswap(k0, r0, k2, r2);
-    cswap(k1, r1, k3, r3);
-    cswap(k1, r1, k2, r2);
-    if (k0 < inf) {
-        if (k3 < inf) stk.push(r3, tc.overflow);
-        if (k2 < inf) stk.push(r2, tc.overflow);
-        if (k1 < inf) stk.push(r1, tc.overflow);
-        cur = r0;
-    } else {
-        cur = stk.pop();
+
+    const uint32_t w3 = __float_as_uint(n0.w);
+    const float sx = __uint_as_float((w3 & 0xffu) << 23), sy = __uint_as_float(((w3 >> 8) & 0xffu) << 23), sz = __uint_as_float(((w3 >> 16) & 0xffu) << 23);
+    const uint32_t imask = w3 >> 24;
+    // plane t = (p + q*s - o) * inv = q * (s*inv) + (p*inv - o*inv)
+    const float ax = sx * r.inv.x, ay = sy * r.inv.y, az = sz * r.inv.z;
+    const float bx = __builtin_fmaf(n0.x, r.inv.x, r.noi.x), by = __builtin_fmaf(n0.y, r.inv.y, r.noi.y), bz = __builtin_fmaf(n0.z, r.inv.z, r.noi.z);
+    // entry / exit planes per axis are chosen once per node from the ray octant (no per-child min/max)
+    const bool px = (r.oct_inv & 4u) != 0u, py = (r.oct_inv & 2u) != 0u, pz = (r.oct_inv & 1u) != 0u;  // direction >= 0
+    const uint32_t lx[2] = {__float_as_uint(n2.x), __float_as_uint(n2.y)}, ly[2] = {__float_as_uint(n2.z), __float_as_uint(n2.w)};
+    const uint32_t lz[2] = {__float_as_uint(n3.x), __float_as_uint(n3.y)}, hx[2] = {__float_as_uint(n3.z), __float_as_uint(n3.w)};
+    const uint32_t hy[2] = {__float_as_uint(n4.x), __float_as_uint(n4.y)}, hz[2] = {__float_as_uint(n4.z), __float_as_uint(n4.w)};
+    const uint32_t nx[2] = {px ? lx[0] : hx[0], px ? lx[1] : hx[1]}, fx[2] = {px ? hx[0] : lx[0], px ? hx[1] : lx[1]};
+    const uint32_t ny[2] = {py ? ly[0] : hy[0], py ? ly[1] : hy[1]}, fy[2] = {py ? hy[0] : ly[0], py ? hy[1] : ly[1]};
+    const uint32_t nz[2] = {pz ? lz[0] : hz[0], pz ? lz[1] : hz[1]}, fz[2] = {pz ? hz[0] : lz[0], pz ? hz[1] : lz[1]};
+    // per-slot hit-mask fields, four slots per word: inner children (low 5 meta bits in 24..31) get
+    // bit 24 + (slot ^ oct_inv), leaves their unary triangle-count mask at their triangle offset
+    const uint32_t oct4 = r.oct_inv * 0x01010101u;
+    uint32_t bits4[2], pos4[2];
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        const uint32_t m4 = __float_as_uint(w ? n1.w : n1.z);
+        const uint32_t inner4 = ((m4 & (m4 << 1)) & 0x10101010u) >> 4;  // 0x01 per inner slot
+        pos4[w] = (m4 ^ (oct4 & (inner4 * 0xffu))) & 0x1f1f1f1fu;
+        bits4[w] = (m4 >> 5) & 0x07070707u;
     }
+    const float tlim = r.tmax * 1.0000004f;
+    uint32_t hitmask = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int w = i >> 2, bsel = i & 3;
+        const float tnx = __builtin_fmaf(ubyte_f32(nx[w], bsel), ax, bx), tfx = __builtin_fmaf(ubyte_f32(fx[w], bsel), ax, bx);
+        const float tny = __builtin_fmaf(ubyte_f32(ny[w], bsel), ay, by), tfy = __builtin_fmaf(ubyte_f32(fy[w], bsel), ay, by);
+        const float tnz = __builtin_fmaf(ubyte_f32(nz[w], bsel), az, bz), tfz = __builtin_fmaf(ubyte_f32(fz[w], bsel), az, bz);
+        const float tn = fmax_(fmax_(tnx, tny), fmax_(tnz, 0.0f));
+        const float tf = fmin_(fmin_(tfx, tfy), fmin_(tfz, tlim)) * 1.0000004f;
+        const uint32_t bits = (bits4[w] >> (8 * bsel)) & 0xffu, pos = (pos4[w] >> (8 * bsel)) & 0xffu;
+        if (tn <= tf) hitmask |= bits << pos;
+    }
+    G.x = __float_as_uint(n1.x);
+    G.y = (hitmask & 0xff000000u) | imask;
+    T.x = __float_as_uint(n1.y);
+    T.y = hitmask & 0x00ffffffu;
 }
 
-// One leaf (cur < 0, cur != sentinel): test its <= 4 triangles, then pop.  Returns true when an
-// any-hit ray found an occluder.
+// Test the next pending triangle of triangle group T.  Returns true when an any-hit ray found an occluder.
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool leaf_step(const float4* __restrict__ tris, TRay& r, Hit& best, int& cur, TravStack& stk, TravCounters& tc) {
-    const uint32_t ref = ~(uint32_t)cur;
-    const uint32_t first = ref >> 2, cnt = (ref & 3u) + 1u;
-    // two triangles per trip: all six 16-byte loads of a pair are in flight together
-    for (uint32_t i = 0; i < cnt; i += 2) {
-        const bool two = i + 1 < cnt;
-        const float4* tp = tris + (size_t)(first + i) * 3;
-        const float4 a0 = tp[0], b0 = tp[1], c0 = tp[2];
-        float4 a1 = a0, b1 = b0, c1 = c0;
-        if (two) {
-            a1 = tp[3];
-            b1 = tp[4];
-            c1 = tp[5];
-        }
-        if (COUNT) tc.tris += two ? 2u : 1u;
-        float t0, t1;
-        const bool h0 = tri_test(r.o, r.d, mk(a0.x, a0.y, a0.z), mk(a0.w, b0.x, b0.y), mk(b0.z, b0.w, c0.x), t0) && t0 > 0.0f;
-        const bool h1 = two && tri_test(r.o, r.d, mk(a1.x, a1.y, a1.z), mk(a1.w, b1.x, b1.y), mk(b1.z, b1.w, c1.x), t1) && t1 > 0.0f;
-        if (ANY) {
-            if ((h0 && t0 < kShadowTmax) || (h1 && t1 < kShadowTmax)) return true;
-        } else {
-            if (h0) {
-                const uint32_t id = __float_as_uint(c0.y);
-                if (t0 < best.t || (t0 == best.t && id < best.id)) {
-                    best.t = t0;
-                    best.li = (int)(first + i);
-                    best.id = id;
-                }
-            }
-            if (h1) {
-                const uint32_t id = __float_as_uint(c1.y);
-                if (t1 < best.t || (t1 == best.t && id < best.id)) {
-                    best.t = t1;
-                    best.li = (int)(first + i + 1);
-                    best.id = id;
-                }
-            }
-            r.tmax = best.t;
+__device__ __forceinline__ bool tri_step(const float4* __restrict__ tris, TRay& r, Hit& best, Group& T, TravCounters& tc) {
+    const uint32_t bit = (uint32_t)__builtin_ctz(T.y);
+    T.y &= T.y - 1u;
+    const uint32_t li = T.x + bit;
+    const float4* tp = tris + (size_t)li * 3;
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    if (COUNT) tc.tris++;
+    float t;
+    if (tri_test(r.o, r.d, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t) && t > 0.0f) {
+        if (ANY) return t < kShadowTmax;
+        const uint32_t id = __float_as_uint(c.y);
+        if (t < best.t || (t == best.t && id < best.id)) {
+            best.t = t;
+            best.li = (int)li;
+            best.id = id;
+            r.tmax = t;
         }
     }
-    cur = stk.pop();
     return false;
 }
 
+__device__ __forceinline__ Group root_group() { return Group{0u, 0x80000000u}; }  // "child 0 of nothing" = node 0
+
 // Whole-ray traversal for one lane (used by the rt_trace_rays test hook; the render kernels drive
-// the same two step functions from a refilling persistent loop).
+// the same step functions from a refilling persistent loop).
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris, v3 o, v3 d, TravStack& stk, Hit& best,
                                          TravCounters& tc) {
     TRay r = make_tray(o, d, ANY ? kShadowTmax : best.t);
     stk.sp = 0;
-    int cur = 0;
-    while (cur != kSentinel) {
-        while (cur >= 0) inner_step<COUNT>(nodes, r, cur, stk, tc);
-        if (cur != kSentinel && leaf_step<ANY, COUNT>(tris, r, best, cur, stk, tc)) return true;
+    Group G = root_group(), T{0u, 0u};
+    for (;;) {
+        if (!has_nodes(G)) {
+            if (stk.sp == 0) return false;
+            G = stk.pop();
+        }
+        node_step<COUNT>(nodes, r, G, T, stk, tc);
+        while (T.y)
+            if (tri_step<ANY, COUNT>(tris, r, best, T, tc)) return true;
     }
-    return false;
 }
 
 // ---- pixel slots ---------------------------------------------------------------------------------
@@ -337,34 +346,35 @@ __global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, P
 // their results and hands them the next rays of the device-resident queue (one atomic per refill,
 // ballot + prefix-popcount to assign entries).  The wave exits when the queue is drained and all its
 // lanes are done, so the grid is sized for the machine, not for the queue length.
-// Between two refill checks every lane makes up to `kInnerPerRound` inner-node steps and one leaf step.
-constexpr int kInnerPerRound = 3;
+// Between two refill checks every lane visits one node and tests up to `kTrisPerRound` triangles.
+constexpr int kTrisPerRound = 2;
 
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(256) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
                                                 const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
                                                 unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min) {
-    extern __shared__ int lds_stack[];  // sk.lds_cap x 256 ints
+    extern __shared__ unsigned long long lds_stack[];  // sk.lds_cap x 256 entries
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
     TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t n = *count_ptr;
-    const int inner_per_round = (int)(refill_min >> 8) ? (int)(refill_min >> 8) : kInnerPerRound;
+    const int tris_per_round = (int)(refill_min >> 8) ? (int)(refill_min >> 8) : kTrisPerRound;
     refill_min &= 0xffu;
     TravCounters tc{0, 0, 0};
 
     TRay r = make_tray(mk(0.0f, 0.0f, 0.0f), mk(0.0f, 1.0f, 0.0f), 0.0f);
     Hit best{0.0f, -1, 0u};
+    Group G{0u, 0u}, T{0u, 0u};
     uint32_t slot = 0;  // closest: path id; any-hit: shadow-queue index
     bool has_ray = false, occluded = false;
     bool exhausted = n == 0;  // wave-uniform
-    int cur = kSentinel;
+    bool alive = false;       // this lane still has traversal work for its ray
 
     for (;;) {
-        const unsigned long long idle = __ballot(cur == kSentinel);
+        const unsigned long long idle = __ballot(!alive);
         if (idle == ~0ull || (!exhausted && (uint32_t)__popcll(idle) >= refill_min)) {
-            if (cur == kSentinel && has_ray) {  // retire
+            if (!alive && has_ray) {  // retire
                 if (ANY) {
                     if (!occluded) {
                         const uint32_t pid = __float_as_uint(st.sh_o[slot].w);
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(256) void pt_trace(const PtScene sc, PtState st, co
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(head, want);
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (cur == kSentinel) {
+                if (!alive) {
                     const uint32_t i = base + (uint32_t)__popcll(idle & lt_mask);
                     if (i < n) {
                         if (ANY) {
@@ -400,21 +410,32 @@ __global__ __launch_bounds__(256) void pt_trace(const PtScene sc, PtState st, co
                             best = Hit{__builtin_inff(), -1, 0xffffffffu};
                         }
                         has_ray = true;
-                        cur = 0;
+                        alive = true;
+                        G = root_group();
+                        T = Group{0u, 0u};
                         stk.sp = 0;
                     }
                 }
                 exhausted = base + want >= n;
             }
-            if (__ballot(cur != kSentinel) == 0ull) break;  // queue drained and every lane retired
+            if (__ballot(alive) == 0ull) break;  // queue drained and every lane retired
         }
+        // node phase: lanes without pending triangles visit their next node
+        if (alive && T.y == 0u) {
+            if (!has_nodes(G)) {
+                if (stk.sp) G = stk.pop();
+                else alive = false;
+            }
+            if (alive) node_step<COUNT>(sc.nodes, r, G, T, stk, tc);
+        }
+        // triangle phase
 #pragma unroll 1
-        for (int it = 0; it < inner_per_round; it++)
-            if (cur >= 0) inner_step<COUNT>(sc.nodes, r, cur, stk, tc);
-        if (cur < 0 && cur != kSentinel) {
-            if (leaf_step<ANY, COUNT>(sc.tris, r, best, cur, stk, tc)) {
-                occluded = true;
-                cur = kSentinel;
+        for (int it = 0; it < tris_per_round; it++) {
+            if (alive && T.y != 0u) {
+                if (tri_step<ANY, COUNT>(sc.tris, r, best, T, tc)) {
+                    occluded = true;
+                    alive = false;
+                }
             }
         }
     }
@@ -574,7 +595,7 @@ __device__ __forceinline__ void trace_one_ray(const PtScene& sc, const float* __
 
 __global__ __launch_bounds__(256) void pt_trace_rays(const PtScene sc, const float* __restrict__ origins, const float* __restrict__ dirs, uint32_t n,
                                                      int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out, const StackCfg sk) {
-    extern __shared__ int lds_stack[];
+    extern __shared__ unsigned long long lds_stack[];
     // grid-stride so the spill columns (one per launched thread) stay within sk.spill_stride
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
     TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
@@ -593,7 +614,7 @@ int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t
     if (stack_cap.lds_cap < 1 || stack_cap.lds_cap > 160 || (size_t)grid * 256u > stack_cap.spill_stride)
         return c->fail(RT_ERR_INVALID, "bad traversal stack configuration");
     const dim3 g(grid), b(256);
-    const size_t lds = (size_t)stack_cap.lds_cap * 256 * sizeof(int);
+    const size_t lds = (size_t)stack_cap.lds_cap * 256 * sizeof(unsigned long long);
     if (any_hit) {
         if (count) hipLaunchKernelGGL((pt_trace<true, true>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
         else hipLaunchKernelGGL((pt_trace<true, false>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
@@ -621,7 +642,7 @@ int launch_pt_resolve(Ctx* c, const PtFrame& f, const PtState& st, float* acc, f
 int launch_pt_trace_rays(Ctx* c, const PtScene& sc, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int* tri_out,
                          const StackCfg& sk, uint32_t grid) {
     if ((size_t)grid * 256u > sk.spill_stride) return c->fail(RT_ERR_INVALID, "bad traversal stack configuration");
-    hipLaunchKernelGGL(pt_trace_rays, dim3(grid), dim3(256), (size_t)sk.lds_cap * 256 * sizeof(int), c->stream, sc, origins, dirs, n, any_hit, t_out,
+    hipLaunchKernelGGL(pt_trace_rays, dim3(grid), dim3(256), (size_t)sk.lds_cap * 256 * sizeof(unsigned long long), c->stream, sc, origins, dirs, n, any_hit, t_out,
                        tri_out, sk);
     RT_HIP(c, hipGetLastError());
     return RT_OK;

@@ -84,13 +84,13 @@ int ensure_wavefront(Ctx* c, uint64_t n_paths, uint64_t n_slots) {
 }
 
 // Traversal stack + persistent grid.  The first lds_cap entries of every lane's stack live in LDS
-// (lds_cap KiB per 256-thread workgroup), which bounds residency at floor(160 KiB / that) workgroups
+// (8-byte entries: 2 x lds_cap KiB per 256-thread workgroup), which bounds residency at floor(160 KiB / that) workgroups
 // per CU, 8 at most (32 waves per CU); the rest of the builder's worst case spills to global memory.
 int stack_config(Ctx* c, uint32_t tune_lds, uint32_t tune_blocks, rt::StackCfg* sk, uint32_t* grid) {
     PtData& pt = c->pt;
     const uint32_t need = std::max<uint32_t>(pt.stack_need, 1u);
-    const uint32_t lds_cap = std::min<uint32_t>(need, tune_lds ? std::min<uint32_t>(tune_lds, 160u) : 16u);
-    const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 160u / lds_cap));
+    const uint32_t lds_cap = std::min<uint32_t>(need, tune_lds ? std::min<uint32_t>(tune_lds, 80u) : 8u);
+    const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 80u / lds_cap));  // 2 KiB per entry per workgroup
     const uint32_t blocks_per_cu = tune_blocks ? std::min<uint32_t>(tune_blocks, fit) : fit;
     *grid = (uint32_t)c->n_cus * blocks_per_cu;
     sk->lds_cap = (int)lds_cap;
@@ -328,7 +328,6 @@ int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const floa
         }
     const auto t0 = std::chrono::steady_clock::now();
     rt::BvhResult bvh;
-    if (const char* lf = std::getenv("RT_BVH_LEAF")) bvh.leaf_max = (uint32_t)std::atoi(lf);  // tuning knob
     if (!rt::build_bvh(v0.data(), e1.data(), e2.data(), n_tris, rt::kBvhMaxDepth, &bvh)) return c->fail(RT_ERR_INVALID, "BVH build failed");
     pt.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
@@ -354,13 +353,13 @@ int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const floa
     for (size_t t = 0; t < n; t++)
         if (emission[3 * t] > 0.0f || emission[3 * t + 1] > 0.0f || emission[3 * t + 2] > 0.0f) lights.push_back(leaf_pos[t]);
 
-    const bool ok = dalloc(pt.d_nodes, (size_t)bvh.n_nodes * 8) && dalloc(pt.d_tris, n * 3) && dalloc(pt.d_albedo, n) && dalloc(pt.d_emission, n) &&
+    const bool ok = dalloc(pt.d_nodes, (size_t)bvh.n_nodes * 5) && dalloc(pt.d_tris, n * 3) && dalloc(pt.d_albedo, n) && dalloc(pt.d_emission, n) &&
                     dalloc(pt.d_lights, std::max<size_t>(lights.size(), 1));
     if (!ok) {
         free_mesh(pt);
         return c->fail(RT_ERR_OOM, "mesh of %u triangles", n_tris);
     }
-    RT_HIP(c, hipMemcpy(pt.d_nodes, bvh.nodes.data(), (size_t)bvh.n_nodes * 128, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(pt.d_nodes, bvh.nodes.data(), (size_t)bvh.n_nodes * 80, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(pt.d_tris, tris.data(), n * 48, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(pt.d_albedo, alb.data(), n * 16, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(pt.d_emission, emi.data(), n * 16, hipMemcpyHostToDevice));

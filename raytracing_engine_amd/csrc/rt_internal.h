@@ -79,7 +79,7 @@ struct ShadeParams {
 enum { PT_CTR_COUNT = 0, PT_CTR_SHADOW_COUNT = 1, PT_CTR_HEAD_CLOSEST = 2, PT_CTR_HEAD_SHADOW = 3, PT_CTR_STRIDE = 4 };
 
 struct PtScene {
-    const float4* nodes;     // 4 x float4 per BVH node (bvh_build.cpp layout)
+    const float4* nodes;     // 5 x float4 (80 B) per compressed 8-wide BVH node (bvh_build.h layout)
     const float4* tris;      // 3 x float4 per triangle, leaf order: v0.xyz e1.x | e1.yz e2.xy | e2.z id - -
     const float4* albedo;    // leaf order
     const float4* emission;  // leaf order
@@ -88,8 +88,8 @@ struct PtScene {
     uint32_t n_tris;
 };
 
-struct StackCfg {  // per-lane traversal stack: lds_cap entries in LDS, then spill_cap entries in global memory
-    int* spill;           // spill_cap x spill_stride ints, entry-major
+struct StackCfg {  // per-lane traversal stack of 8-byte entries: lds_cap in LDS, then spill_cap in global memory
+    unsigned long long* spill;  // spill_cap x spill_stride entries, entry-major
     size_t spill_stride;  // = threads of the persistent grid
     int lds_cap, spill_cap;
 };
@@ -129,7 +129,7 @@ struct PtData {  // device residency of one mesh + the wavefront buffers
     float4* d_emission = nullptr;
     uint32_t* d_lights = nullptr;
     uint32_t stack_need = 0;  // worst-case traversal stack occupancy reported by the builder
-    int* d_spill = nullptr;
+    unsigned long long* d_spill = nullptr;
     size_t spill_words = 0;
     // wavefront buffers, sized for cap_paths
     uint64_t cap_paths = 0;

@@ -25,6 +25,6 @@ for k, v in sorted(agg.items()):
         wc = g("SQ_WAVE_CYCLES")
         print(f"    -> VALU active/wave-cycle {g('SQ_ACTIVE_INST_VALU', 0) / wc:.3f}  wait_any {g('SQ_WAIT_ANY', 0) / wc:.3f}  wait_inst {g('SQ_WAIT_INST_ANY', 0) / wc:.3f}")
     if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
-        print(f"    -> lanes active per VALU cycle {g('SQ_THREAD_CYCLES_VALU') / g('SQ_ACTIVE_INST_VALU') / 4:.1f} / 64 (quad-cycle units)")
+        print(f"    -> lanes active per VALU instruction {g('SQ_THREAD_CYCLES_VALU') / g('SQ_INSTS_VALU', 1):.1f} / 64")
     if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and (g("TCC_HIT_sum") + g("TCC_MISS_sum")) > 0:
         print(f"    -> L2 hit rate {g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')):.3f}")
