@@ -152,7 +152,7 @@ class TriWorkload:
 
     def describe(self):
         st = self.r.pt_stats()
-        return {"workload": f"{self.name}: {self.n_tris} random triangles (edge +-{self.edge}) + 1 emissive quad, BVH4 "
+        return {"workload": f"{self.name}: {self.n_tris} random triangles (edge +-{self.edge}) + 1 emissive quad, compressed BVH8 "
                             f"({st['n_nodes']} nodes, depth {st['bvh_depth']}), {self.width}x{self.height}, {self.spp} spp, "
                             f"{self.bounces} bounce + NEE, path B wavefront path tracer",
                 "width": self.width, "height": self.height, "spp": self.spp, "bounces": self.bounces, "tile": 64,
@@ -168,7 +168,7 @@ class TriWorkload:
 
     def roofline(self):
         """Dominant kernel = pt_trace<closest>.  Algorithmic bytes per launch: every BVH
-        4-wide node fetched = 128 B, every triangle tested = 48 B, per ray 32 B ray read + 8 B hit write + 4 B
+        compressed 8-wide node fetched = 80 B, every triangle tested = 48 B, per ray 32 B ray read + 8 B hit write + 4 B
         queue entry; counts come from the kernel's own instrumented twin (count_traversal)."""
         r = self.r
         prm = r.pt_params(spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky, count_traversal=True)
@@ -187,8 +187,8 @@ class TriWorkload:
         cfg.profile_stages = 0
         r.set_config(cfg)
         closest_rays = ct["camera_rays"] + ct["bounce_rays"]
-        bytes_closest = ct["nodes_visited"] * 128.0 + ct["tris_tested"] * 48.0 + closest_rays * 44.0
-        bytes_shadow = ct["shadow_nodes_visited"] * 128.0 + ct["shadow_tris_tested"] * 48.0 + ct["shadow_rays"] * 48.0
+        bytes_closest = ct["nodes_visited"] * 80.0 + ct["tris_tested"] * 48.0 + closest_rays * 44.0
+        bytes_shadow = ct["shadow_nodes_visited"] * 80.0 + ct["shadow_tris_tested"] * 48.0 + ct["shadow_rays"] * 48.0
         n_launch = st["launches_trace_closest"]
         ms = acc["ms_trace_closest"] / n_launch
         achieved = bytes_closest / (acc["ms_trace_closest"] * 1e-3) / 1e9
