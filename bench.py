@@ -31,6 +31,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="tri1m_1080p_4spp", help="tri1m_1080p_4spp (metric config) | spheres8_1080p_4spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="debug only: all ranks share cuda:0 and gather through host memory over gloo (exercises the N>1 "
+                         "control flow on a 1-GPU box; the line it prints is marked rehearsal and is not a measurement)")
     return ap.parse_args()
 
 
@@ -234,11 +237,16 @@ def main():
 
     import raytracing_engine_amd as R
 
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     r = R.Renderer(local_rank)  # raises when librt_amd.so / the GPU is missing: no fallback
     wl = WORKLOADS[args.workload](R, r)
@@ -250,16 +258,28 @@ def main():
     if world > 1:
         mine = torch.zeros((tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev)
         gathered = torch.empty((world, tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev) if rank == 0 else None
-        r.set_stream(torch.cuda.current_stream().cuda_stream)  # render, gather and de-tile in stream order
+        # One explicit (non-null) stream carries render -> RCCL gather -> de-tile in order.  The null
+        # stream must not be used here: rt_set_stream(NULL) selects the context's own non-blocking
+        # stream, which does not synchronise with torch's default stream.
+        side = torch.cuda.Stream(device=dev)
+        r.set_stream(side.cuda_stream)
 
     def step():
         if world == 1:
             wl.step(frame.data_ptr(), False)
         else:
-            wl.step(mine.data_ptr(), True)
-            R.host.gather_tiles(mine, gathered, rank, dist)
-            if rank == 0:
-                r.detile_device(gathered.data_ptr(), world, tiles_per_rank, frame.data_ptr())
+            with torch.cuda.stream(side):
+                wl.step(mine.data_ptr(), True)                   # enqueued on `side` by the context
+                if args.rehearse_one_gpu:  # gloo gathers host tensors
+                    side.synchronize()
+                    host_all = torch.empty(gathered.shape) if rank == 0 else None
+                    R.host.gather_tiles(mine.cpu(), host_all, rank, dist)
+                    if rank == 0:
+                        gathered.copy_(host_all)
+                else:
+                    R.host.gather_tiles(mine, gathered, rank, dist)  # RCCL waits for / is waited on by `side`
+                if rank == 0:
+                    r.detile_device(gathered.data_ptr(), world, tiles_per_rank, frame.data_ptr())
 
     def fence():
         r.synchronize()
@@ -277,7 +297,7 @@ def main():
     dt = time.perf_counter() - t0
 
     rays = wl.rays_per_step()
-    tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device="cpu" if args.rehearse_one_gpu else dev)
     if world > 1:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -292,9 +312,19 @@ def main():
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
                "config": dict(wl.describe(), parallelism=f"tile-split x{world}" if world > 1 else "single GPU",
                               rays_per_step=int(rays))}
+        if args.rehearse_one_gpu:
+            out["rehearsal"] = "all ranks on one GPU, gloo gather through host memory: NOT a measurement"
+            # the de-tiled frame of the split render must equal a single-context render of the same frame
+            import numpy as np
+            split = frame.cpu().numpy().copy()
         if world > 1:
+            torch.cuda.synchronize()
             r.set_stream(None)
         r.set_partition(0, 1)
+        if args.rehearse_one_gpu and world > 1:
+            wl.step(frame.data_ptr(), False)
+            r.synchronize()
+            out["rehearsal_split_equals_single"] = bool((frame.cpu().numpy() == split).all())
         if world == 1:
             out["roofline"] = wl.roofline()
             if not args.no_cpu_baseline:
