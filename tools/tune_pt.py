@@ -18,6 +18,7 @@ ap.add_argument("--refill", default="16")
 ap.add_argument("--blocks", default="0")
 ap.add_argument("--lds", default="0")
 ap.add_argument("--k", default="0")
+ap.add_argument("--gate", default="0")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--scene", default="soup")
 a = ap.parse_args()
@@ -37,17 +38,19 @@ _cr = _c["camera_rays"] + _c["bounce_rays"]
 print(f"per closest ray: nodes {_c['nodes_visited'] / _cr:.1f} tris {_c['tris_tested'] / _cr:.1f}; per shadow ray: nodes "
       f"{_c['shadow_nodes_visited'] / max(_c['shadow_rays'], 1):.1f} tris {_c['shadow_tris_tested'] / max(_c['shadow_rays'], 1):.1f}; "
       f"rays cam {_c['camera_rays']} bounce {_c['bounce_rays']} shadow {_c['shadow_rays']}")
-for refill in [int(x) for x in a.refill.split(",")]:
-  for kk in [int(x) for x in a.k.split(",")]:
-   for lds in [int(x) for x in a.lds.split(",")]:
-    for blocks in [int(x) for x in a.blocks.split(",")]:
-        prm = r.pt_params(spp=4, bounces=1, seed=1, sky=(0.2, 0.2, 0.25), tune_refill_min=refill | (kk << 8), tune_blocks_per_cu=blocks, tune_lds_stack=lds)
+import itertools
+
+ints = lambda v: [int(x) for x in v.split(",")]
+for refill, kk, gate, lds, blocks in itertools.product(ints(a.refill), ints(a.k), ints(a.gate), ints(a.lds), ints(a.blocks)):
+    prm = r.pt_params(spp=4, bounces=1, seed=1, sky=(0.2, 0.2, 0.25), tune_refill_min=refill | (kk << 8) | (gate << 16),
+                      tune_blocks_per_cu=blocks, tune_lds_stack=lds)
+    r.render_pt(pos=pos, params=prm)
+    acc = {}
+    for _ in range(a.reps):
         r.render_pt(pos=pos, params=prm)
-        acc = {}
-        for _ in range(a.reps):
-            r.render_pt(pos=pos, params=prm)
-            st = r.pt_stats()
-            for k in ("ms_total", "ms_generate", "ms_trace_closest", "ms_shade", "ms_trace_shadow", "ms_resolve"):
-                acc[k] = acc.get(k, 0.0) + st[k] / a.reps
-        rays = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
-        print(f"refill={refill:2d} k={kk} lds={lds:2d} blocks={blocks} Mrays/s={rays / acc['ms_total'] / 1e3:8.1f} " + " ".join(f"{k[3:]}={v:7.3f}" for k, v in acc.items()), flush=True)
+        st = r.pt_stats()
+        for k in ("ms_total", "ms_generate", "ms_trace_closest", "ms_shade", "ms_trace_shadow", "ms_resolve"):
+            acc[k] = acc.get(k, 0.0) + st[k] / a.reps
+    rays = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
+    print(f"refill={refill:2d} k={kk} gate={gate:2d} lds={lds:2d} blocks={blocks} Mrays/s={rays / acc['ms_total'] / 1e3:8.1f} "
+          + " ".join(f"{k[3:]}={v:7.3f}" for k, v in acc.items()), flush=True)
