@@ -215,7 +215,8 @@ struct Cw8Builder {
     std::vector<uint32_t>& order8;          // final leaf order -> triangle id
     uint32_t depth = 0;
 
-    static constexpr float kCostNode = 1.0f, kCostPrim = 0.3f;
+    static constexpr float kCostNode = 1.0f;
+    float kCostPrim = 0.8f;
     struct Dp {
         float cost[8];     // cost[i], i = 1..7: subtree as a forest of <= i roots
         uint8_t split[9];  // split[i], i = 2..8: roots given to the left child in D(n,i)
@@ -507,7 +508,7 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
     std::vector<uint32_t> order2;
     order2.swap(out->order);
     out->order.reserve(n);
-    Cw8Builder cw{binary, order2, out->nodes, out->order, 0, {}};
+    Cw8Builder cw{binary, order2, out->nodes, out->order, 0, out->cost_prim, {}};
     cw.build();
     if (out->order.size() != n) return false;
     out->n_nodes = (uint32_t)(out->nodes.size() / 20);

@@ -21,6 +21,8 @@ namespace rt {
 struct BvhResult {
     std::vector<uint32_t> nodes;  // 20 words (80 B) per compressed 8-wide node
     std::vector<uint32_t> order;  // leaf-order position -> original triangle index
+    float cost_prim = 0.8f;       // in: SAH cost of a triangle test relative to a node visit (collapse DP);
+                                  // measured on the bench scene: 0.3 -> 1615, 0.6 -> 1794, 1.0 -> 1799 Mrays/s
     uint32_t n_nodes = 0;
     uint32_t depth = 0;           // levels of 8-wide inner nodes (root = 1)
     uint32_t stack_need = 0;      // worst-case traversal stack occupancy (entries)
