@@ -198,7 +198,9 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
     }
 
     const unsigned long long hits = __ballot(hit);
-    if (lane == 0 && hits) atomicAdd((unsigned long long*)&counters[0], (unsigned long long)__popcll(hits));
+    // hit-pixel statistics: one atomic per wave, spread over 1024 slots (a single hot word serves only
+    // ~90 atomics/us chip-wide and made this kernel atomic-bound); the host sums the slots
+    if (lane == 0 && hits) atomicAdd((unsigned long long*)&counters[blockIdx.x & 1023u], (unsigned long long)__popcll(hits));
 
     if (inside) {
         const size_t idx = p.tile_major ? ((size_t)k * (RT_TILE * RT_TILE) + (size_t)ly * RT_TILE + lx)

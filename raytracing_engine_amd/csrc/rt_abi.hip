@@ -158,7 +158,7 @@ int render_common(Ctx* c, const float rot[4], const float pos[3], uint32_t spp, 
     if (int rc = bind(c)) return rc;
 
     const bool stage_events = c->cfg.profile_stages != 0;
-    RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(uint64_t), c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 1024 * sizeof(uint64_t), c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     for (uint32_t s = 0; s < spp; s++) {
         // per-stage events only bracket the last sample (ev_stage is reused per sample)
@@ -175,8 +175,9 @@ int render_common(Ctx* c, const float rot[4], const float pos[3], uint32_t spp, 
     c->stats.cone_threads = cone_threads * spp;  // upper bound when partitioned
     if (sync) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
-        uint64_t counters[8] = {};
-        RT_HIP(c, hipMemcpy(counters, c->d_counters, sizeof counters, hipMemcpyDeviceToHost));
+        uint64_t slots[1024], counters[1] = {0};
+        RT_HIP(c, hipMemcpy(slots, c->d_counters, sizeof slots, hipMemcpyDeviceToHost));
+        for (uint64_t v : slots) counters[0] += v;
         uint64_t owned_px = 0;
         {  // pixels inside the frame that belong to this rank's tiles
             const rt::Partition& pt = c->part;
@@ -278,7 +279,7 @@ int rt_create(rt_ctx** out, int device_ordinal) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 8 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 1024 * sizeof(uint64_t));
     for (uint32_t i = 0; e == hipSuccess && i < RT_MAX_LEVELS + 2; i++) {
         hipEvent_t ev;
         e = hipEventCreate(&ev);

@@ -159,7 +159,7 @@ struct Ctx {
     uint32_t dims[RT_MAX_LEVELS][2] = {};
     float* d_level[RT_MAX_LEVELS] = {};
     float* d_rgb = nullptr;         // full frame, f32 x 3
-    uint64_t* d_counters = nullptr;  // [0] hit pixels
+    uint64_t* d_counters = nullptr;  // 1024 slots of hit-pixel counts, summed on the host
     Partition part{0, 1, 0, 0};
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
