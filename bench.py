@@ -119,17 +119,19 @@ class SpheresWorkload:
         n = 2
         O.render_a(sc, 64, 64)  # warm the OpenMP pool
         t0 = time.perf_counter()
-        rays = 0
-        for s in range(self.spp):
-            i, j = s % n, s // n
-            jit = (((np.float32(2 * i + 1) / np.float32(n)) - np.float32(1)) / np.float32(self.width),
-                   ((np.float32(2 * j + 1) / np.float32(n)) - np.float32(1)) / np.float32(self.height))
-            ct = O.render_a(sc, self.width, self.height, rot=self.rot, pos=self.pos, jitter=jit, want_levels=False,
-                            threads=threads)["counters"]
-            rays += self.width * self.height + ct["shadow_rays"]
+        rays, reps = 0, 0
+        while time.perf_counter() - t0 < 2.0:  # >= 2 s wall on every granted core
+            for s in range(self.spp):
+                i, j = s % n, s // n
+                jit = (((np.float32(2 * i + 1) / np.float32(n)) - np.float32(1)) / np.float32(self.width),
+                       ((np.float32(2 * j + 1) / np.float32(n)) - np.float32(1)) / np.float32(self.height))
+                ct = O.render_a(sc, self.width, self.height, rot=self.rot, pos=self.pos, jitter=jit, want_levels=False,
+                                threads=threads)["counters"]
+                rays += self.width * self.height + ct["shadow_rays"]
+            reps += 1
         dt = time.perf_counter() - t0
         return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                "sample": f"the full workload once ({self.spp} spp x {self.width}x{self.height}) with oracle A "
+                "sample": f"the full workload {reps}x ({self.spp} spp x {self.width}x{self.height}) with oracle A "
                           f"(OpenMP, {threads} threads), {dt:.2f} s"}
 
 
