@@ -7,16 +7,16 @@
 //
 // Structure (one launch per ray stage, all queue sizes stay on the device):
 //   pt_generate       camera rays for every (pixel, sample) of the owned tiles -> path state + queue 0
-//   pt_trace<closest> persistent waves pull 64-ray chunks off the queue, BVH2 traversal with a
-//                     per-lane stack in LDS, ray/triangle tests, writes (t, triangle)
+//   pt_trace<closest> persistent waves with per-lane refill from the device-resident queue; traversal
+//                     of a compressed 8-wide BVH (80-byte nodes, five 16-byte fetches per node) with a
+//                     per-lane stack of node groups in LDS, ray/triangle tests, writes (t, triangle)
 //   pt_shade          emission / sky / next-event estimation / cosine bounce; survivors are appended to
 //                     the next queue and shadow rays to the shadow queue with wave ballot +
-//                     prefix-popcount compaction (one atomic per wave)
+//                     prefix-popcount compaction (one atomic per 1024-thread workgroup)
 //   pt_trace<any>     shadow rays: any-hit traversal, unoccluded contributions added to the path
 //   pt_resolve        per pixel: samples summed in index order, divided by spp
 // Memory: path state is SoA of float4 (16 B per lane per array = widest coalesced access), BVH nodes
-// are 64-byte child-pair records (one fetch per traversal step), triangles 48-byte records in leaf
-// order.
+// are 80-byte quantised records (bvh_build.h), triangles 48-byte records in leaf order.
 #include "rt_device_math.h"
 #include "rt_internal.h"
 
