@@ -215,6 +215,8 @@ def _libb():
         L.orb_scene_destroy.argtypes = [C.c_void_p]
         L.orb_render.argtypes = [C.c_void_p, C.POINTER(PtParams), fp, C.POINTER(PtCounters), C.c_int, C.c_int]
         L.orb_render.restype = C.c_int
+        L.orb_render_rows.argtypes = [C.c_void_p, C.POINTER(PtParams), C.c_uint32, C.c_uint32, fp, C.POINTER(PtCounters), C.c_int, C.c_int]
+        L.orb_render_rows.restype = C.c_int
         L.orb_closest_hit.argtypes = [C.c_void_p, fp, fp, fp, C.c_int]
         L.orb_closest_hit.restype = C.c_int32
         L.orb_occluded.argtypes = [C.c_void_p, fp, fp, C.c_int]
@@ -248,7 +250,7 @@ class TriScene:
             self._h = None
 
     def render(self, width, height, spp=1, bounces=1, seed=1, rot=(0, 0, 0, 1), pos=(0, 0, 0), ratio=None,
-               sky=(0.0, 0.0, 0.0), ray_eps=1e-3, use_bvh=True, threads=0):
+               sky=(0.0, 0.0, 0.0), ray_eps=1e-3, use_bvh=True, threads=0, rows=None):
         p = PtParams()
         p.width, p.height, p.spp, p.bounces, p.seed = width, height, spp, bounces, seed
         if ratio is None:
@@ -258,9 +260,10 @@ class TriScene:
         p.pos[:] = [float(np.float32(x)) for x in pos]
         p.sky[:] = [float(np.float32(x)) for x in sky]
         p.ray_eps = ray_eps
-        rgb = np.zeros((height, width, 3), np.float32)
+        row0, row1 = rows if rows is not None else (0, height)
+        rgb = np.zeros((row1 - row0, width, 3), np.float32)
         ct = PtCounters()
-        rc = _libb().orb_render(self._h, C.byref(p), rgb.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ct), int(use_bvh), threads)
+        rc = _libb().orb_render_rows(self._h, C.byref(p), row0, row1, rgb.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ct), int(use_bvh), threads)
         if rc:
             raise RuntimeError(f"orb_render failed: {rc}")
         return rgb, ct.as_dict()

@@ -141,6 +141,8 @@ void orb_scene_destroy(orb_scene* s);
 /* rgb: width*height*3, row 0 = py 0.  use_bvh = 0: brute force over all triangles (small
  * scenes only; independent cross-check of the BVH path).  threads <= 0: all. */
 int orb_render(const orb_scene* s, const orb_params* p, float* rgb, orb_counters* ct, int use_bvh, int threads);
+/* rows [row0,row1) only; rgb: (row1-row0)*width*3 */
+int orb_render_rows(const orb_scene* s, const orb_params* p, uint32_t row0, uint32_t row1, float* rgb, orb_counters* ct, int use_bvh, int threads);
 
 /* single-ray hooks for the known-answer tests: closest hit (returns triangle index or -1,
  * *t_out = distance) and occlusion of the open segment (origin, origin + dir) */

@@ -393,7 +393,14 @@ static void trace_path(const orb_scene* s, const orb_params* p, uint32_t px, uin
 }
 
 int orb_render(const orb_scene* s, const orb_params* p, float* rgb, orb_counters* ct_out, int use_bvh, int threads) {
-    if (!s || !p || !rgb || p->width == 0 || p->height == 0 || p->spp == 0) return -1;
+    return orb_render_rows(s, p, 0, p ? p->height : 0, rgb, ct_out, use_bvh, threads);
+}
+
+/* rows [row0, row1) of the frame only (rgb holds (row1-row0)*width*3 floats): lets tests compare a
+ * band of a full-size frame, which works because the RNG is keyed by the global pixel index */
+int orb_render_rows(const orb_scene* s, const orb_params* p, uint32_t row0, uint32_t row1, float* rgb, orb_counters* ct_out, int use_bvh,
+                    int threads) {
+    if (!s || !p || !rgb || p->width == 0 || p->height == 0 || p->spp == 0 || row0 >= row1 || row1 > p->height) return -1;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
 #else
@@ -401,7 +408,7 @@ int orb_render(const orb_scene* s, const orb_params* p, float* rgb, orb_counters
 #endif
     uint64_t cam = 0, bnc = 0, shd = 0, nv = 0, tt = 0;
 #pragma omp parallel for schedule(dynamic, 2) num_threads(threads) reduction(+ : cam, bnc, shd, nv, tt)
-    for (uint32_t py = 0; py < p->height; py++) {
+    for (uint32_t py = row0; py < row1; py++) {
         orb_counters ct;
         memset(&ct, 0, sizeof ct);
         for (uint32_t px = 0; px < p->width; px++) {
@@ -411,7 +418,7 @@ int orb_render(const orb_scene* s, const orb_params* p, float* rgb, orb_counters
                 trace_path(s, p, px, py, sidx, use_bvh, L, &ct);
                 acc[0] += L[0]; acc[1] += L[1]; acc[2] += L[2];
             }
-            float* o = rgb + ((size_t)py * p->width + px) * 3;
+            float* o = rgb + ((size_t)(py - row0) * p->width + px) * 3;
             o[0] = acc[0] / (float)p->spp; o[1] = acc[1] / (float)p->spp; o[2] = acc[2] / (float)p->spp;
         }
         cam += ct.camera_rays; bnc += ct.bounce_rays; shd += ct.shadow_rays; nv += ct.nodes_visited; tt += ct.tris_tested;

@@ -184,3 +184,7 @@ def test_full_hd_properties(renderer):
     a2 = renderer.render_pt(params=prm)
     assert np.array_equal(a1, a2) and np.isfinite(a1).all() and (a1 >= 0).all()
     assert st["camera_rays"] == 1920 * 1080 * 4 and st["bounce_rays"] <= st["camera_rays"] and st["stack_overflow"] == 0
+    # band parity at full size: the RNG is keyed by the global pixel index, so the oracle can render
+    # just rows 520..536 of the 1920x1080 frame and must reproduce those rows of the GPU frame exactly
+    band, _ = O.TriScene(v, a, e).render(1920, 1080, spp=4, bounces=1, seed=1, sky=(0.2, 0.2, 0.25), rows=(520, 536))
+    assert np.array_equal(a1[520:536], band)
