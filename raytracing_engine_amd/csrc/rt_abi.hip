@@ -277,6 +277,7 @@ int rt_create(rt_ctx** out, int device_ordinal) {
     rt_default_config(&c->cfg);
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 1024 * sizeof(uint64_t));
@@ -302,12 +303,14 @@ void rt_destroy(rt_ctx* ctx) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     free_frame(c);
     rt::pt_free(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     for (auto ev : c->ev_stage) (void)hipEventDestroy(ev);
     if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
     if (c->ev_end) (void)hipEventDestroy(c->ev_end);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

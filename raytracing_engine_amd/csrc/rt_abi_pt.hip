@@ -96,7 +96,8 @@ int stack_config(Ctx* c, uint32_t tune_lds, uint32_t tune_blocks, rt::StackCfg* 
     sk->lds_cap = (int)lds_cap;
     sk->spill_cap = (int)(need - lds_cap);
     sk->spill_stride = (size_t)c->n_cus * 8u * 256u;  // covers every grid this function can return
-    const size_t words = std::max<size_t>(1, (size_t)sk->spill_cap) * sk->spill_stride;
+    const size_t half = std::max<size_t>(1, (size_t)sk->spill_cap) * sk->spill_stride;
+    const size_t words = 2 * half;  // second half: the shadow kernel when it overlaps the next closest-hit kernel
     if (words > pt.spill_words) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
         dfree(pt.d_spill);
@@ -105,6 +106,7 @@ int stack_config(Ctx* c, uint32_t tune_lds, uint32_t tune_blocks, rt::StackCfg* 
         pt.spill_words = words;
     }
     sk->spill = pt.d_spill;
+    pt.spill_half = half;
     return RT_OK;
 }
 
@@ -185,6 +187,13 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     uint64_t cam = 0, bnc = 0, shd = 0;
     uint32_t launches_closest = 0, launches_shadow = 0;
+    // per-stage timing needs the stages back to back on one stream
+    const bool overlap = !tm.on && !prm->tune_no_overlap && c->aux_stream != nullptr;
+    bool shadow_pending = false;
+    if (overlap && !pt.ev_shaded) {
+        RT_HIP(c, hipEventCreateWithFlags(&pt.ev_shaded, hipEventDisableTiming));
+        RT_HIP(c, hipEventCreateWithFlags(&pt.ev_shadowed, hipEventDisableTiming));
+    }
     std::vector<uint32_t> h_ctr((size_t)rt::PT_CTR_STRIDE * (prm->bounces + 2));
 
     for (uint32_t s0 = 0; s0 < prm->spp; s0 += spp_batch) {
@@ -221,15 +230,42 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent, stack_cap, refill_min)) return rc;
             tm.end();
             launches_closest++;
+            if (shadow_pending) {  // shade(d) adds sky/emission after shadow(d-1)'s contribution
+                RT_HIP(c, hipStreamWaitEvent(c->stream, pt.ev_shadowed, 0));
+                shadow_pending = false;
+            }
             tm.begin(2);
             if (int rc = rt::launch_pt_shade(c, sc, f, pt.st, q, ctr_d + rt::PT_CTR_COUNT, d, qn, ctr_n, grid_stride)) return rc;
             tm.end();
             if (pt.n_lights) {
+                // shadow(d) only adds to the paths' radiance; closest(d+1) only reads rays: they are
+                // independent, so the shadow kernel runs on the auxiliary stream beside the next
+                // closest-hit kernel (each persistent kernel fills the other's tail).  shade(d+1) and
+                // resolve read the radiance and therefore wait for it (keeps the per-path sum order).
+                rt::StackCfg sk2 = stack_cap;
+                hipStream_t main_stream = c->stream;
+                if (overlap) {
+                    sk2.spill = stack_cap.spill + pt.spill_half;
+                    RT_HIP(c, hipEventRecord(pt.ev_shaded, main_stream));
+                    RT_HIP(c, hipStreamWaitEvent(c->aux_stream, pt.ev_shaded, 0));
+                    c->stream = c->aux_stream;
+                }
                 tm.begin(3);
-                if (int rc = rt::launch_pt_trace(c, sc, pt.st, nullptr, ctr_n + rt::PT_CTR_SHADOW_COUNT, ctr_n + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, true, count, grid_persistent, stack_cap, refill_min)) return rc;
+                int rc = rt::launch_pt_trace(c, sc, pt.st, nullptr, ctr_n + rt::PT_CTR_SHADOW_COUNT, ctr_n + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, true, count, grid_persistent, sk2, refill_min);
                 tm.end();
+                if (overlap) {
+                    hipError_t e = rc ? hipSuccess : hipEventRecord(pt.ev_shadowed, c->aux_stream);
+                    c->stream = main_stream;
+                    if (rc) return rc;
+                    RT_HIP(c, e);
+                    shadow_pending = true;
+                } else if (rc) return rc;
                 launches_shadow++;
             }
+        }
+        if (shadow_pending) {
+            RT_HIP(c, hipStreamWaitEvent(c->stream, pt.ev_shadowed, 0));
+            shadow_pending = false;
         }
         tm.begin(4);
         if (int rc = rt::launch_pt_resolve(c, f, pt.st, pt.d_acc, dst_dev, tile_major)) return rc;
@@ -285,6 +321,9 @@ void pt_free(Ctx* c) {
     free_mesh(c->pt);
     dfree(c->pt.d_ctr);
     dfree(c->pt.d_stats);
+    if (c->pt.ev_shaded) (void)hipEventDestroy(c->pt.ev_shaded);
+    if (c->pt.ev_shadowed) (void)hipEventDestroy(c->pt.ev_shadowed);
+    c->pt.ev_shaded = c->pt.ev_shadowed = nullptr;
 }
 }  // namespace rt
 
@@ -302,6 +341,7 @@ int rt_default_pt_params(rt_pt_params* p) {
     p->tune_refill_min = 0;
     p->tune_blocks_per_cu = 0;
     p->tune_lds_stack = 0;
+    p->tune_no_overlap = 0;
     return RT_OK;
 }
 

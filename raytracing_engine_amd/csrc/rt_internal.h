@@ -130,7 +130,8 @@ struct PtData {  // device residency of one mesh + the wavefront buffers
     uint32_t* d_lights = nullptr;
     uint32_t stack_need = 0;  // worst-case traversal stack occupancy reported by the builder
     unsigned long long* d_spill = nullptr;
-    size_t spill_words = 0;
+    size_t spill_words = 0, spill_half = 0;
+    hipEvent_t ev_shaded = nullptr, ev_shadowed = nullptr;  // ordering between the main and the auxiliary stream
     // wavefront buffers, sized for cap_paths
     uint64_t cap_paths = 0;
     uint32_t cap_depth = 0;
@@ -147,6 +148,7 @@ struct Ctx {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;  // path B: shadow kernel beside the next closest-hit kernel
     std::string err;
 
     rt_config cfg{};
