@@ -181,6 +181,7 @@ typedef struct rt_pt_stats {
     uint64_t camera_rays, bounce_rays, shadow_rays; /* last render: rays handed to BVH traversal */
     uint64_t nodes_visited, tris_tested;            /* closest-hit launches; last render, count_traversal = 1 only */
     uint64_t shadow_nodes_visited, shadow_tris_tested; /* any-hit (shadow) launches, same condition */
+    uint64_t wave_rounds, alive_lane_rounds;           /* closest-hit launches: traversal rounds per wave summed, lanes holding a live ray summed */
     float ms_total;            /* last render: HIP-event time around the stage loop */
     float ms_generate, ms_trace_closest, ms_shade, ms_trace_shadow, ms_resolve; /* profile_stages = 1 only */
     uint32_t launches_trace_closest, launches_trace_shadow;

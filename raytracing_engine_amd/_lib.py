@@ -70,6 +70,7 @@ class PtStats(C.Structure):  # rt_pt_stats
                 ("stack_need", C.c_uint32), ("bvh_build_ms", C.c_float), ("stack_overflow", C.c_uint32), ("camera_rays", C.c_uint64),
                 ("bounce_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("tris_tested", C.c_uint64), ("shadow_nodes_visited", C.c_uint64), ("shadow_tris_tested", C.c_uint64),
+                ("wave_rounds", C.c_uint64), ("alive_lane_rounds", C.c_uint64),
                 ("ms_total", C.c_float), ("ms_generate", C.c_float),
                 ("ms_trace_closest", C.c_float), ("ms_shade", C.c_float), ("ms_trace_shadow", C.c_float),
                 ("ms_resolve", C.c_float), ("launches_trace_closest", C.c_uint32), ("launches_trace_shadow", C.c_uint32)]

@@ -38,11 +38,13 @@ _cr = _c["camera_rays"] + _c["bounce_rays"]
 print(f"per closest ray: nodes {_c['nodes_visited'] / _cr:.1f} tris {_c['tris_tested'] / _cr:.1f}; per shadow ray: nodes "
       f"{_c['shadow_nodes_visited'] / max(_c['shadow_rays'], 1):.1f} tris {_c['shadow_tris_tested'] / max(_c['shadow_rays'], 1):.1f}; "
       f"rays cam {_c['camera_rays']} bounce {_c['bounce_rays']} shadow {_c['shadow_rays']}")
+print(f"closest kernels: wave-rounds {_c['wave_rounds']}, alive lanes/round {_c['alive_lane_rounds'] / max(_c['wave_rounds'], 1):.1f}, "
+      f"lanes in node phase/round {_c['nodes_visited'] / max(_c['wave_rounds'], 1):.1f}, lanes in tri phase/round {_c['tris_tested'] / max(_c['wave_rounds'], 1):.1f}")
 import itertools
 
 ints = lambda v: [int(x) for x in v.split(",")]
 for refill, kk, gate, lds, blocks in itertools.product(ints(a.refill), ints(a.k), ints(a.gate), ints(a.lds), ints(a.blocks)):
-    prm = r.pt_params(spp=4, bounces=1, seed=1, sky=(0.2, 0.2, 0.25), tune_refill_min=refill | (kk << 8) | (gate << 16),
+    prm = r.pt_params(spp=4, bounces=1, seed=1, sky=(0.2, 0.2, 0.25), tune_refill_min=refill | (kk << 8) | (gate << 16),  # gate byte = local refill threshold
                       tune_blocks_per_cu=blocks, tune_lds_stack=lds)
     r.render_pt(pos=pos, params=prm)
     acc = {}
