@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="tri1m_1080p_4spp", help="tri1m_1080p_4spp (metric config) | spheres8_1080p_4spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # run under rocprofv3 by measure_traffic()
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child runs (roofline.traffic = null)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="debug only: all ranks share cuda:0 and gather through host memory over gloo (exercises the N>1 "
                          "control flow on a 1-GPU box; the line it prints is marked rehearsal and is not a measurement)")
@@ -50,6 +52,45 @@ def host_threads():
     return n
 
 
+def measure_traffic(workload, kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC counters, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE passes
+    (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2), with --kernel-trace only; on gfx950 FETCH_SIZE
+    tallies 128-byte requests as 64 bytes, so the read side is doubled (calibrated for wide streaming
+    reads; for these 16-byte gathers it is an upper bound of the correction).  Each pass profiles a
+    child process that runs two steps of the same workload.  Returns None when rocprofv3 is unusable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None
+    kb = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__), "--traffic-child", "--workload", workload]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=600, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+                        vals.append(float(row["Counter_Value"]))
+            shutil.rmtree(d, ignore_errors=True)
+            if not vals:
+                return None
+            kb[counter] = sum(vals) / len(vals)
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    return {"bytes_per_launch": kb["FETCH_SIZE"] * 1024.0 * 2.0 + kb["WRITE_SIZE"] * 1024.0,
+            "fetch_size_kb_raw": round(kb["FETCH_SIZE"], 1), "write_size_kb_raw": round(kb["WRITE_SIZE"], 1),
+            "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as read"}
+
+
 # ---- workloads -----------------------------------------------------------------------------
 class SpheresWorkload:
     """BASELINE.json configs[1]: the 8-sphere Cornell-style scene, 1920x1080, 4 spp, path A
@@ -58,6 +99,7 @@ class SpheresWorkload:
     name = "spheres8_1080p_4spp"
     width, height, spp = 1920, 1080, 4
     dtype = "f32"
+    dominant_kernel = "cone_level_kernel"  # all eight level launches averaged (the per-frame dominant stage)
 
     def __init__(self, R, renderer):
         self.R, self.r = R, renderer
@@ -145,6 +187,7 @@ class TriWorkload:
     width, height, spp, bounces, seed = 1920, 1080, 4, 1, 1
     sky = (0.2, 0.2, 0.25)
     dtype = "f32"
+    dominant_kernel = "pt_trace<false, false>"
 
     def __init__(self, R, renderer):
         self.R, self.r = R, renderer
@@ -252,6 +295,13 @@ def main():
 
     r = R.Renderer(local_rank)  # raises when librt_amd.so / the GPU is missing: no fallback
     wl = WORKLOADS[args.workload](R, r)
+    if args.traffic_child:  # profiled by measure_traffic(): two plain steps, nothing printed
+        buf = torch.empty((wl.height, wl.width, 3), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            wl.step(buf.data_ptr(), False)
+        r.synchronize()
+        r.close()
+        return
     r.set_partition(rank, world)
     tx, ty, owned = r.tile_info()
     tiles_per_rank = -(-(tx * ty) // world)
@@ -329,6 +379,11 @@ def main():
             out["rehearsal_split_equals_single"] = bool((frame.cpu().numpy() == split).all())
         if world == 1:
             out["roofline"] = wl.roofline()
+            if not args.no_traffic:
+                tr = measure_traffic(args.workload, wl.dominant_kernel)
+                if tr:
+                    out["roofline"]["traffic"] = tr["bytes_per_launch"]
+                    out["roofline"]["traffic_detail"] = tr
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
