@@ -99,7 +99,7 @@ class SpheresWorkload:
     name = "spheres8_1080p_4spp"
     width, height, spp = 1920, 1080, 4
     dtype = "f32"
-    dominant_kernel = "cone_level_kernel"  # all eight level launches averaged (the per-frame dominant stage)
+    dominant_kernel = "shade_kernel"
 
     def __init__(self, R, renderer):
         self.R, self.r = R, renderer
@@ -141,8 +141,13 @@ class SpheresWorkload:
         lv, sh = lv / reps, sh / reps
         dims = self.r.level_info()
         last = len(dims) - 1
-        kernels = {f"cone_level_kernel(level {last})": (lv[last], dims[last][0] * dims[last][1] * 8.0),
-                   "shade_kernel": (sh, self.width * self.height * 16.0)}
+        fused = st["ms_fused"]
+        if fused > 0:  # one-launch pyramid: every level texel stored once (4 B); shade: 4 B depth + 12 B rgb
+            kernels = {"pyramid_tile_kernel": (fused, sum(w * h for w, h in dims) * 4.0),
+                       "shade_kernel": (sh, self.width * self.height * 16.0)}
+        else:
+            kernels = {f"cone_level_kernel(level {last})": (lv[last], dims[last][0] * dims[last][1] * 8.0),
+                       "shade_kernel": (sh, self.width * self.height * 16.0)}
         name = max(kernels, key=lambda k: kernels[k][0])
         ms, nbytes = kernels[name]
         achieved = nbytes / (ms * 1e-3) / 1e9

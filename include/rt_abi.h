@@ -77,6 +77,9 @@ typedef struct rt_config {
     float ray_radius;     /* RAY_RADIUS = 0.01    fragment.glsl:37 */
     uint32_t max_steps;   /* cap on either march loop so every wave terminates (default 1<<20; 0 = none) */
     uint32_t profile_stages; /* 1: bracket every kernel with HIP events (rt_get_stats.stage_ms) */
+    uint32_t fuse_levels;    /* 0 (default): one launch per level, the reference's schedule (src/main.rs:300-316);
+                                1: the whole depth pyramid in one launch (parent levels kept in LDS; measured slower).
+                                Same results; in fused mode level texels without a descendant inside the frame are left 0 */
 } rt_config;
 
 typedef struct rt_stats {
@@ -89,7 +92,8 @@ typedef struct rt_stats {
     float    ms_total;         /* last call: HIP-event time around the whole stage loop */
     float    ms_cone;          /* last call: sum over level kernels (profile_stages=1 only) */
     float    ms_shade;         /* last call: shade kernel(s) (profile_stages=1 only) */
-    float    ms_level[RT_MAX_LEVELS]; /* last call, last sample (profile_stages=1 only) */
+    float    ms_level[RT_MAX_LEVELS]; /* last call, last sample (profile_stages=1, fuse_levels=0 only) */
+    float    ms_fused;         /* last call, last sample: the one-launch pyramid kernel (profile_stages=1, fuse_levels=1) */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

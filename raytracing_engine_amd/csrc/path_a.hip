@@ -31,11 +31,11 @@ __device__ __forceinline__ bool owns_pixel_tile(const Partition& part, uint32_t 
 
 // ---- shaders/compute.glsl:34-68 ---------------------------------------------------------------
 template <int N>
-__device__ __forceinline__ float trace_cone(const SphereSet& S, v3 origin, v3 step, float threshold, float render_dist,
+__device__ __forceinline__ float trace_cone(const float4 (&sph)[RT_MAX_OBJECTS], v3 origin, v3 step, float threshold, float render_dist,
                                             uint32_t max_steps) {
     float distances[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) distances[i] = sphere_sdf(origin, S.s[i]);  // :37-39
+    for (int i = 0; i < N; i++) distances[i] = sphere_sdf(origin, sph[i]);  // :37-39
 
     float len = 0.0f, last = 0.0f;
     uint32_t it = 0;
@@ -46,8 +46,10 @@ __device__ __forceinline__ float trace_cone(const SphereSet& S, v3 origin, v3 st
         const float radius = (len + 1.0f) * threshold;  // :50
 #pragma unroll
         for (int i = 0; i < N; i++) {  // :51-57
+            // kept as a branch: evaluating all N distances and selecting (more ILP) was measured 1.5x
+            // slower - the correctly rounded sqrt sequences are not free
             distances[i] -= last;
-            if (distances[i] <= radius) distances[i] = sphere_sdf(position, S.s[i]);
+            if (distances[i] <= radius) distances[i] = sphere_sdf(position, sph[i]);
             dist = fmin_(dist, distances[i]);
         }
         last = fmax_(dist, 0.0f);  // :59
@@ -61,6 +63,23 @@ __device__ __forceinline__ float trace_cone(const SphereSet& S, v3 origin, v3 st
 }
 
 // ---- shaders/compute.glsl:70-87 ---------------------------------------------------------------
+// One invocation of compute.glsl:main for level pixel (gx, gy); `len0` is 1.0 at level 0 (:79) or the
+// parent texel (:80-82).
+template <int N>
+__device__ __forceinline__ float cone_pixel(const float4 (&sph)[RT_MAX_OBJECTS], const Camera cam, float isx, float isy, uint32_t gx, uint32_t gy, float len0,
+                                            float render_dist, uint32_t max_steps) {
+    // :71-72  (gid*2 + 1) * imageSize - 1, then * ratio   (jitter = 0 for the reference's sample)
+    float nx = __builtin_fmaf((float)(gx * 2u + 1u), isx, -1.0f) + cam.jitter[0];
+    float ny = __builtin_fmaf((float)(gy * 2u + 1u), isy, -1.0f) + cam.jitter[1];
+    nx *= cam.ratio[0];
+    ny *= cam.ratio[1];
+    const float threshold = (1.4142135f * 8.0f) * isx;  // :75
+    const v3 step = normalize(rotate_q(cam.rot[0], cam.rot[1], cam.rot[2], cam.rot[3], mk(nx, 1.0f, ny)));  // :77
+    const v3 pos = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
+    const float len = len0 + trace_cone<N>(sph, fma3(step, len0, pos), step, threshold, render_dist, max_steps);  // :84
+    return fmax_(len, 0.0f);                                                                                    // :86
+}
+
 template <int N>
 __global__ __launch_bounds__(256) void cone_level_kernel(const SphereSet S, const ConeLevelParams p,
                                                          const float* __restrict__ parent, float* __restrict__ out) {
@@ -74,20 +93,8 @@ __global__ __launch_bounds__(256) void cone_level_kernel(const SphereSet S, cons
         if (!owns_pixel_tile(p.part, (tx * 8u) << p.shift, (ty * 8u) << p.shift, p.width, p.height)) return;
     }
     const uint32_t gx = tx * 8u + (lane & 7u), gy = ty * 8u + (lane >> 3);
-
-    // :71-72  (gid*2 + 1) * imageSize - 1, then * ratio   (jitter = 0 for the reference's sample)
-    float nx = __builtin_fmaf((float)(gx * 2u + 1u), p.image_size[0], -1.0f) + p.cam.jitter[0];
-    float ny = __builtin_fmaf((float)(gy * 2u + 1u), p.image_size[1], -1.0f) + p.cam.jitter[1];
-    nx *= p.cam.ratio[0];
-    ny *= p.cam.ratio[1];
-    const float threshold = (1.4142135f * 8.0f) * p.image_size[0];  // :75
-    const v3 step = normalize(rotate_q(p.cam.rot[0], p.cam.rot[1], p.cam.rot[2], p.cam.rot[3], mk(nx, 1.0f, ny)));  // :77
-
-    float len = 1.0f;                                                                   // :79
-    if (p.level > 0) len = parent[(size_t)(gy >> 1) * p.parent_w + (gx >> 1)];           // :80-82
-    const v3 pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
-    len += trace_cone<N>(S, fma3(step, len, pos), step, threshold, p.render_dist, p.max_steps);  // :84
-    out[(size_t)gy * p.w + gx] = fmax_(len, 0.0f);                                               // :86
+    const float len0 = p.level > 0 ? parent[(size_t)(gy >> 1) * p.parent_w + (gx >> 1)] : 1.0f;  // :79-82
+    out[(size_t)gy * p.w + gx] = cone_pixel<N>(S.s, p.cam, p.image_size[0], p.image_size[1], gx, gy, len0, p.render_dist, p.max_steps);
 }
 
 // ---- shaders/fragment.glsl:89-121 -------------------------------------------------------------
@@ -117,7 +124,103 @@ __device__ __forceinline__ float shadow_ray(const float4 (&sphere)[RT_MAX_OBJECT
     return nearest;  // :120
 }
 
+// Element i (wave-uniform) of an 8-entry kernarg array by compare/select over constant indices.  A
+// dynamically indexed by-value kernel argument makes the compiler copy the whole struct to scratch
+// (576 B per lane, +40 VGPRs); constant indices keep it in SGPRs.  For the same reason the inlined
+// per-pixel functions take these structs BY VALUE: a reference to a by-value kernel argument pins
+// the copy in memory, a value is split into scalars again after inlining.
+__device__ __forceinline__ float4 pick8(const float4 (&a)[8], uint32_t i) {
+    float4 v = a[0];
+#pragma unroll
+    for (uint32_t k = 1; k < 8; k++)
+        if (i == k) v = a[k];
+    return v;
+}
+
 // ---- shaders/fragment.glsl:127-187 ------------------------------------------------------------
+// One invocation of fragment.glsl:main for full-resolution pixel (px, py) whose depth is total_dist.
+// Returns true for a hit pixel; rgb = 0 for a miss (:137-140).
+template <int N>
+__device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams p, uint32_t px, uint32_t py, float total_dist, float& r, float& g,
+                                            float& b) {
+    r = g = b = 0.0f;
+    if (!(total_dist < p.render_dist)) return false;  // :137-140
+    // :129-133  gl_FragCoord.xy * 2 / cs.view - 1.0   (gl_FragCoord = pixel + 0.5)
+    float nx = (((float)px + 0.5f) * 2.0f) / p.view[0] - 1.0f + p.cam.jitter[0];
+    float ny = (((float)py + 0.5f) * 2.0f) / p.view[1] - 1.0f + p.cam.jitter[1];
+    nx *= p.cam.ratio[0];
+    ny *= p.cam.ratio[1];
+    const v3 step = normalize(rotate_q(p.cam.rot[0], p.cam.rot[1], p.cam.rot[2], p.cam.rot[3], mk(nx, 1.0f, ny)));
+    const v3 pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+    const v3 position = fma3(step, total_dist, pos);  // :142
+
+    // :144-156 nearest sphere (strict '<', first wins ties); material index = object index
+    float dist = sphere_sdf(position, S.sphere[0]);
+    float4 obj = S.sphere[0];
+    float4 mat = S.mat_color_ambient[0];
+    float shine = S.mat_shine[0];
+#pragma unroll
+    for (int i = 1; i < N; i++) {
+        const float nd = sphere_sdf(position, S.sphere[i]);
+        if (nd < dist) {
+            dist = nd;
+            obj = S.sphere[i];
+            mat = S.mat_color_ambient[i];
+            shine = S.mat_shine[i];
+        }
+    }
+
+    const float cam_dist = length(position - pos);                                                    // :162
+    const float cam_fall = fmax_(p.cam_fall_off * __builtin_fmaf(cam_dist, cam_dist, 1.0f), 1.0f);   // :163
+    const v3 normal = normalize(position - mk(obj.x, obj.y, obj.z));                                  // :166
+    const v3 cam_dir = -step;
+    const float normal_fall = fmax_(dot(normal, cam_dir), 0.0f);  // :167
+
+    for (uint32_t i = 0; i < S.light_count; i++) {  // :170-186
+        const float4 lp = pick8(S.light_pos, i), lc = pick8(S.light_color, i);
+        const v3 lpos = mk(lp.x, lp.y, lp.z);
+        const v3 light_dir = normalize(lpos - position);   // :173
+        const float light_dist = length(position - lpos);  // :174
+        const float soft = fmin_(shadow_ray<N>(S.sphere, position + light_dir, light_dir, light_dist, p.ray_radius, p.max_steps), 1.0f);  // :176
+        const float light_fall = fmax_((p.light_fall_off * light_dist) * light_dist, 1.0f);                                               // :178
+        const float diffuse = fmax_(dot(normal, light_dir), 0.0f);                                                                        // :180
+        // :181, :47-50  reflect(I,N) = I - 2*dot(N,I)*N with I = -lightDir
+        const v3 inc = -light_dir;
+        const float kk = 2.0f * dot(normal, inc);
+        const v3 refl = mk(__builtin_fmaf(-kk, normal.x, inc.x), __builtin_fmaf(-kk, normal.y, inc.y), __builtin_fmaf(-kk, normal.z, inc.z));
+        const float base = dot(refl, cam_dir);
+        // pow(x<=0, y) is undefined in GLSL; defined as 0 here
+        const float spec = base > 0.0f ? fmax_(diffuse * __builtin_powf(base, shine), 0.0f) : 0.0f;
+        const float s = fmax_(diffuse + spec, 0.0f);  // :183
+        const float dr = ((s * lc.x) / light_fall) * soft;
+        const float dg = ((s * lc.y) / light_fall) * soft;
+        const float db = ((s * lc.z) / light_fall) * soft;
+        // :185  (ambient + direct) / camDistFallOff * normalFallOff * mat.color
+        r = __builtin_fmaf(((mat.w + dr) / cam_fall) * normal_fall, mat.x, r);
+        g = __builtin_fmaf(((mat.w + dg) / cam_fall) * normal_fall, mat.y, g);
+        b = __builtin_fmaf(((mat.w + db) / cam_fall) * normal_fall, mat.z, b);
+    }
+    return true;
+}
+
+// Store one shaded sample: overwrite, or add to the running sum (samples in index order:
+// ((s0 + s1) + s2) + ...), dividing by spp after the last one.
+__device__ __forceinline__ void store_sample(const ShadeParams p, float* o, float r, float g, float b) {
+    if (p.mode & 1u) {
+        r = o[0] + r;
+        g = o[1] + g;
+        b = o[2] + b;
+    }
+    if (p.mode & 2u) {
+        r = r / p.spp;
+        g = g / p.spp;
+        b = b / p.spp;
+    }
+    o[0] = r;
+    o[1] = g;
+    o[2] = b;
+}
+
 // Grid: 16 workgroups per owned framebuffer tile; every wave shades one 8x8 block of the tile.
 template <int N>
 __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const ShadeParams p, const float* __restrict__ depth,
@@ -132,70 +235,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
     const bool inside = px < p.width && py < p.height;
 
     float r = 0.0f, g = 0.0f, b = 0.0f;
-    bool hit = false;
-    if (inside) {
-        // :129-133  gl_FragCoord.xy * 2 / cs.view - 1.0   (gl_FragCoord = pixel + 0.5)
-        float nx = (((float)px + 0.5f) * 2.0f) / p.view[0] - 1.0f + p.cam.jitter[0];
-        float ny = (((float)py + 0.5f) * 2.0f) / p.view[1] - 1.0f + p.cam.jitter[1];
-        nx *= p.cam.ratio[0];
-        ny *= p.cam.ratio[1];
-        const v3 step = normalize(rotate_q(p.cam.rot[0], p.cam.rot[1], p.cam.rot[2], p.cam.rot[3], mk(nx, 1.0f, ny)));
-        const float total_dist = depth[(size_t)py * p.depth_w + px];  // :135
-        hit = total_dist < p.render_dist;                             // :137-140 (miss -> rgb 0)
-        if (hit) {
-            const v3 pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
-            const v3 position = fma3(step, total_dist, pos);  // :142
-
-            // :144-156 nearest sphere (strict '<', first wins ties); material index = object index
-            float dist = sphere_sdf(position, S.sphere[0]);
-            float4 obj = S.sphere[0];
-            float4 mat = S.mat_color_ambient[0];
-            float shine = S.mat_shine[0];
-#pragma unroll
-            for (int i = 1; i < N; i++) {
-                const float nd = sphere_sdf(position, S.sphere[i]);
-                if (nd < dist) {
-                    dist = nd;
-                    obj = S.sphere[i];
-                    mat = S.mat_color_ambient[i];
-                    shine = S.mat_shine[i];
-                }
-            }
-
-            const float cam_dist = length(position - pos);                                                    // :162
-            const float cam_fall = fmax_(p.cam_fall_off * __builtin_fmaf(cam_dist, cam_dist, 1.0f), 1.0f);   // :163
-            const v3 normal = normalize(position - mk(obj.x, obj.y, obj.z));                                  // :166
-            const v3 cam_dir = -step;
-            const float normal_fall = fmax_(dot(normal, cam_dir), 0.0f);  // :167
-
-            for (uint32_t i = 0; i < S.light_count; i++) {  // :170-186
-                const float4 lp = S.light_pos[i], lc = S.light_color[i];
-                const v3 lpos = mk(lp.x, lp.y, lp.z);
-                const v3 light_dir = normalize(lpos - position);   // :173
-                const float light_dist = length(position - lpos);  // :174
-                const float soft =
-                    fmin_(shadow_ray<N>(S.sphere, position + light_dir, light_dir, light_dist, p.ray_radius, p.max_steps), 1.0f);  // :176
-                const float light_fall = fmax_((p.light_fall_off * light_dist) * light_dist, 1.0f);  // :178
-                const float diffuse = fmax_(dot(normal, light_dir), 0.0f);                           // :180
-                // :181, :47-50  reflect(I,N) = I - 2*dot(N,I)*N with I = -lightDir
-                const v3 inc = -light_dir;
-                const float kk = 2.0f * dot(normal, inc);
-                const v3 refl = mk(__builtin_fmaf(-kk, normal.x, inc.x), __builtin_fmaf(-kk, normal.y, inc.y),
-                                   __builtin_fmaf(-kk, normal.z, inc.z));
-                const float base = dot(refl, cam_dir);
-                // pow(x<=0, y) is undefined in GLSL; defined as 0 here
-                const float spec = base > 0.0f ? fmax_(diffuse * __builtin_powf(base, shine), 0.0f) : 0.0f;
-                const float s = fmax_(diffuse + spec, 0.0f);  // :183
-                const float dr = ((s * lc.x) / light_fall) * soft;
-                const float dg = ((s * lc.y) / light_fall) * soft;
-                const float db = ((s * lc.z) / light_fall) * soft;
-                // :185  (ambient + direct) / camDistFallOff * normalFallOff * mat.color
-                r = __builtin_fmaf(((mat.w + dr) / cam_fall) * normal_fall, mat.x, r);
-                g = __builtin_fmaf(((mat.w + dg) / cam_fall) * normal_fall, mat.y, g);
-                b = __builtin_fmaf(((mat.w + db) / cam_fall) * normal_fall, mat.z, b);
-            }
-        }
-    }
+    const bool hit = inside && shade_pixel<N>(S, p, px, py, depth[(size_t)py * p.depth_w + px], r, g, b);  // :135
 
     const unsigned long long hits = __ballot(hit);
     // hit-pixel statistics: one atomic per wave, spread over 1024 slots (a single hot word serves only
@@ -203,22 +243,79 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
     if (lane == 0 && hits) atomicAdd((unsigned long long*)&counters[blockIdx.x & 1023u], (unsigned long long)__popcll(hits));
 
     if (inside) {
-        const size_t idx = p.tile_major ? ((size_t)k * (RT_TILE * RT_TILE) + (size_t)ly * RT_TILE + lx)
-                                        : ((size_t)py * p.width + px);
-        float* o = dst + idx * 3;
-        if (p.mode & 1u) {  // sample accumulation, fixed order: ((s0 + s1) + s2) + ...
-            r = o[0] + r;
-            g = o[1] + g;
-            b = o[2] + b;
+        const size_t idx = p.tile_major ? ((size_t)k * (RT_TILE * RT_TILE) + (size_t)ly * RT_TILE + lx) : ((size_t)py * p.width + px);
+        store_sample(p, dst + idx * 3, r, g, b);
+    }
+}
+
+// ---- fused pyramid kernel -------------------------------------------------------------------------
+// The reference records one dispatch per pyramid level (src/main.rs:300-316) because Vulkan needs a
+// barrier between levels.  A pixel's chain of ancestors is private to its 32x32 neighbourhood, so on
+// gfx950 the whole pyramid CAN be one launch: a 256-thread workgroup owns a 32x32 block of
+// full-resolution pixels and walks the pyramid top-down for just that block (1,1,..,2x2,4x4,8x8,
+// 16x16,32x32 texels; coarse texels shared with neighbouring blocks are recomputed, they are a
+// handful), keeping the parent level in LDS.  Seven kernel boundaries disappear.
+// MEASURED (1920x1080, 8 spheres): 0.35 ms against 0.28 ms for the eight per-level launches - the
+// frame's critical path is the sum of the per-level march latencies either way, and the per-level
+// launches spread each level over the whole chip while a workgroup spends its coarse levels with
+// one lane busy.  So this schedule is OFF by default (rt_config.fuse_levels) and kept as the
+// tested alternative.  (Fusing the shading pass as well needs more scalar registers than a wave has
+// - scene, lights, materials and nine levels of parameters are all wave-uniform - and spilled.)
+// Level images are written only where a texel has a descendant inside the frame; the others are
+// never read by anything and stay 0.
+constexpr uint32_t kFusedTile = 32;
+__device__ __forceinline__ void tile_coords(uint32_t idx, uint32_t ext, uint32_t& lx, uint32_t& ly) {
+    if (ext >= 8u) {  // 8x8 blocks: one wave iteration = one compact block (similar march lengths)
+        const uint32_t blk = idx >> 6, in = idx & 63u, bw = ext >> 3;
+        lx = (blk % bw) * 8u + (in & 7u);
+        ly = (blk / bw) * 8u + (in >> 3);
+    } else {
+        lx = idx % ext;
+        ly = idx / ext;
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void pyramid_tile_kernel(const SphereSet S, const PyramidParams fp) {
+    __shared__ float lds[2][kFusedTile * kFusedTile];  // ping-pong: parent level / current level
+    const uint32_t k = blockIdx.x >> 2, quad = blockIdx.x & 3u;
+    const uint32_t tile = fp.part.rank + k * fp.part.n_ranks;
+    const uint32_t tile_y = tile / fp.part.tiles_x, tile_x = tile - tile_y * fp.part.tiles_x;
+    const uint32_t X0 = tile_x * RT_TILE + (quad & 1u) * kFusedTile, Y0 = tile_y * RT_TILE + (quad >> 1) * kFusedTile;
+    if (X0 >= fp.width || Y0 >= fp.height) return;  // whole block outside the frame (workgroup-uniform)
+
+    const uint32_t last = fp.count - 1u;
+    for (uint32_t lvl = 0; lvl <= last; lvl++) {
+        const uint32_t shift = last - lvl;
+        const uint32_t ext = (kFusedTile >> shift) ? (kFusedTile >> shift) : 1u, pext = (ext >> 1) ? (ext >> 1) : 1u;
+        const uint32_t ox = X0 >> shift, oy = Y0 >> shift;
+        float* cur = lds[lvl & 1u];
+        const float* par = lds[(lvl & 1u) ^ 1u];
+        // per-level parameters by compare/select over constant indices (see pick8)
+        float isx = fp.image_size[0][0], isy = fp.image_size[0][1];
+        float* img = fp.level[0];
+        uint32_t pitch = fp.level_w[0];
+#pragma unroll
+        for (uint32_t q = 1; q < RT_MAX_LEVELS; q++)
+            if (lvl == q) {
+                isx = fp.image_size[q][0];
+                isy = fp.image_size[q][1];
+                img = fp.level[q];
+                pitch = fp.level_w[q];
+            }
+        for (uint32_t idx = threadIdx.x; idx < ext * ext; idx += 256u) {
+            uint32_t lx, ly;
+            tile_coords(idx, ext, lx, ly);
+            const uint32_t gx = ox + lx, gy = oy + ly;
+            float v = 0.0f;
+            if ((gx << shift) < fp.width && (gy << shift) < fp.height) {  // has a descendant inside the frame
+                const float len0 = lvl ? par[(ly >> 1) * pext + (lx >> 1)] : 1.0f;
+                v = cone_pixel<N>(S.s, fp.cam, isx, isy, gx, gy, len0, fp.render_dist, fp.max_steps);
+                img[(size_t)gy * pitch + gx] = v;
+            }
+            cur[ly * ext + lx] = v;
         }
-        if (p.mode & 2u) {
-            r = r / p.spp;
-            g = g / p.spp;
-            b = b / p.spp;
-        }
-        o[0] = r;
-        o[1] = g;
-        o[2] = b;
+        __syncthreads();
     }
 }
 
@@ -302,6 +399,35 @@ int launch_shade(Ctx* c, const ShadeSet& S, uint32_t n_obj, const ShadeParams& p
         case 6: shade_launch_n<6>(c->stream, grid, S, p, depth, dst, counters); break;
         case 7: shade_launch_n<7>(c->stream, grid, S, p, depth, dst, counters); break;
         default: shade_launch_n<8>(c->stream, grid, S, p, depth, dst, counters); break;
+    }
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+template <int N>
+static void pyramid_launch_n(hipStream_t st, dim3 grid, const SphereSet& S, const PyramidParams& fp) {
+    hipLaunchKernelGGL(pyramid_tile_kernel<N>, grid, dim3(256), 0, st, S, fp);
+}
+
+int launch_pyramid_fused(Ctx* c, const SphereSet& S, uint32_t n_obj, const PyramidParams& fp) {
+    if (n_obj < 1 || n_obj > RT_MAX_OBJECTS) return c->fail(RT_ERR_INVALID, "objCount %u out of [1,8]", n_obj);
+    const Partition& part = fp.part;
+    if (part.n_ranks == 0 || part.rank >= part.n_ranks || fp.count < 1 || fp.count > RT_MAX_LEVELS) return c->fail(RT_ERR_INVALID, "bad frame parameters");
+    for (uint32_t i = 0; i < fp.count; i++)
+        if (!fp.level[i] || fp.level_w[i] == 0) return c->fail(RT_ERR_INVALID, "level %u has no image", i);
+    const uint32_t total = part.tiles_x * part.tiles_y;
+    const uint32_t owned = total > part.rank ? (total - part.rank + part.n_ranks - 1u) / part.n_ranks : 0u;
+    if (owned == 0) return RT_OK;
+    const dim3 grid(owned * 4u);  // four 32x32 blocks per 64x64 framebuffer tile
+    switch (n_obj) {
+        case 1: pyramid_launch_n<1>(c->stream, grid, S, fp); break;
+        case 2: pyramid_launch_n<2>(c->stream, grid, S, fp); break;
+        case 3: pyramid_launch_n<3>(c->stream, grid, S, fp); break;
+        case 4: pyramid_launch_n<4>(c->stream, grid, S, fp); break;
+        case 5: pyramid_launch_n<5>(c->stream, grid, S, fp); break;
+        case 6: pyramid_launch_n<6>(c->stream, grid, S, fp); break;
+        case 7: pyramid_launch_n<7>(c->stream, grid, S, fp); break;
+        default: pyramid_launch_n<8>(c->stream, grid, S, fp); break;
     }
     RT_HIP(c, hipGetLastError());
     return RT_OK;

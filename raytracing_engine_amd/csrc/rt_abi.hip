@@ -96,31 +96,51 @@ int enqueue_sample(Ctx* c, const float rot[4], const float pos[3], uint32_t s, u
     cam.jitter[0] = ((float)(2u * si + 1u) / (float)n_strata - 1.0f) / (float)c->width;
     cam.jitter[1] = ((float)(2u * sj + 1u) / (float)n_strata - 1.0f) / (float)c->height;
 
+    const uint32_t count = c->level_count;
+    uint32_t ev = 0;
     rt::SphereSet spheres;
     fill_sphere_set(c->scene, &spheres);
-    const uint32_t count = c->level_count;
-    const bool partitioned = c->part.n_ranks > 1;
-    uint32_t ev = 0;
-    for (uint32_t i = 0; i < count; i++) {  // src/main.rs:300-316
-        rt::ConeLevelParams p{};
-        p.cam = cam;
-        const float pw = (float)(1u << (count - 1u - i));  // :303-305
-        p.image_size[0] = pw / (float)c->width;
-        p.image_size[1] = pw / (float)c->height;
-        p.level = i;
-        p.w = c->dims[i][0];
-        p.h = c->dims[i][1];
-        p.parent_w = i ? c->dims[i - 1][0] : 0;
-        p.shift = count - 1u - i;
-        p.width = c->width;
-        p.height = c->height;
-        p.render_dist = c->cfg.render_dist;
-        p.max_steps = c->cfg.max_steps;
-        p.part = c->part;
-        p.partitioned = partitioned ? 1u : 0u;
+    if (c->cfg.fuse_levels) {  // one launch for the whole pyramid (path_a.hip pyramid_tile_kernel)
+        rt::PyramidParams fp{};
+        fp.cam = cam;
+        fp.width = c->width;
+        fp.height = c->height;
+        fp.render_dist = c->cfg.render_dist;
+        fp.max_steps = c->cfg.max_steps;
+        fp.part = c->part;
+        fp.count = count;
+        for (uint32_t i = 0; i < count; i++) {
+            const float pw = (float)(1u << (count - 1u - i));  // src/main.rs:303-305
+            fp.image_size[i][0] = pw / (float)c->width;
+            fp.image_size[i][1] = pw / (float)c->height;
+            fp.level_w[i] = c->dims[i][0];
+            fp.level[i] = c->d_level[i];
+        }
         if (stage_events) RT_HIP(c, hipEventRecord(c->ev_stage[ev++], c->stream));
-        int rc = rt::launch_cone_level(c, spheres, c->scene.objCount, p, i ? c->d_level[i - 1] : nullptr, c->d_level[i]);
-        if (rc) return rc;
+        if (int rc = rt::launch_pyramid_fused(c, spheres, c->scene.objCount, fp)) return rc;
+    } else {
+        const bool partitioned = c->part.n_ranks > 1;
+        for (uint32_t i = 0; i < count; i++) {  // src/main.rs:300-316
+            rt::ConeLevelParams p{};
+            p.cam = cam;
+            const float pw = (float)(1u << (count - 1u - i));  // :303-305
+            p.image_size[0] = pw / (float)c->width;
+            p.image_size[1] = pw / (float)c->height;
+            p.level = i;
+            p.w = c->dims[i][0];
+            p.h = c->dims[i][1];
+            p.parent_w = i ? c->dims[i - 1][0] : 0;
+            p.shift = count - 1u - i;
+            p.width = c->width;
+            p.height = c->height;
+            p.render_dist = c->cfg.render_dist;
+            p.max_steps = c->cfg.max_steps;
+            p.part = c->part;
+            p.partitioned = partitioned ? 1u : 0u;
+            if (stage_events) RT_HIP(c, hipEventRecord(c->ev_stage[ev++], c->stream));
+            int rc = rt::launch_cone_level(c, spheres, c->scene.objCount, p, i ? c->d_level[i - 1] : nullptr, c->d_level[i]);
+            if (rc) return rc;
+        }
     }
     if (stage_events) RT_HIP(c, hipEventRecord(c->ev_stage[ev++], c->stream));
 
@@ -193,7 +213,12 @@ int render_common(Ctx* c, const float rot[4], const float pos[3], uint32_t spp, 
         RT_HIP(c, hipEventElapsedTime(&c->stats.ms_total, c->ev_begin, c->ev_end));
         c->stats.ms_cone = c->stats.ms_shade = 0.0f;
         std::memset(c->stats.ms_level, 0, sizeof c->stats.ms_level);
-        if (stage_events) {
+        c->stats.ms_fused = 0.0f;
+        if (stage_events && c->cfg.fuse_levels) {
+            RT_HIP(c, hipEventElapsedTime(&c->stats.ms_fused, c->ev_stage[0], c->ev_stage[1]));
+            c->stats.ms_cone = c->stats.ms_fused;
+            RT_HIP(c, hipEventElapsedTime(&c->stats.ms_shade, c->ev_stage[1], c->ev_stage[2]));
+        } else if (stage_events) {
             for (uint32_t i = 0; i < c->level_count; i++) {
                 RT_HIP(c, hipEventElapsedTime(&c->stats.ms_level[i], c->ev_stage[i], c->ev_stage[i + 1]));
                 c->stats.ms_cone += c->stats.ms_level[i];
@@ -229,6 +254,7 @@ int rt_default_config(rt_config* cfg) {
     cfg->ray_radius = 0.01f;      // shaders/fragment.glsl:37
     cfg->max_steps = 1u << 20;
     cfg->profile_stages = 0;
+    cfg->fuse_levels = 0;  // measured slower than one launch per level (path_a.hip)
     return RT_OK;
 }
 
@@ -356,7 +382,7 @@ int rt_resize(rt_ctx* ctx, uint32_t width, uint32_t height, const float ratio[2]
     for (uint32_t i = 0; i < count; i++) {
         level_dims_for(width, height, count, i, &c->dims[i][0], &c->dims[i][1]);
         const size_t bytes = (size_t)c->dims[i][0] * c->dims[i][1] * sizeof(float);
-        if (hipMalloc((void**)&c->d_level[i], bytes) != hipSuccess) {
+        if (hipMalloc((void**)&c->d_level[i], bytes) != hipSuccess || hipMemset(c->d_level[i], 0, bytes) != hipSuccess) {
             free_frame(c);
             return c->fail(RT_ERR_OOM, "pyramid level %u (%zu bytes)", i, bytes);
         }

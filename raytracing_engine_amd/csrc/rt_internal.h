@@ -75,6 +75,19 @@ struct ShadeParams {
     float spp;
 };
 
+// One-launch pyramid: every level for a 32x32 pixel block per workgroup (path_a.hip)
+struct PyramidParams {
+    Camera cam;
+    uint32_t width, height;
+    float render_dist;
+    uint32_t max_steps;
+    Partition part;
+    uint32_t count;                        // pyramid levels
+    float image_size[RT_MAX_LEVELS][2];    // per level: 2^(count-1-level) / view
+    uint32_t level_w[RT_MAX_LEVELS];       // row pitch of each level image
+    float* level[RT_MAX_LEVELS];           // level images in HBM
+};
+
 // ---- path B (triangles + BVH + path tracing) -------------------------------------
 enum { PT_CTR_COUNT = 0, PT_CTR_SHADOW_COUNT = 1, PT_CTR_HEAD_CLOSEST = 2, PT_CTR_HEAD_SHADOW = 3, PT_CTR_STRIDE = 4 };
 
@@ -193,6 +206,7 @@ int launch_cone_level(Ctx* c, const SphereSet& spheres, uint32_t n_obj, const Co
                       float* out);
 int launch_shade(Ctx* c, const ShadeSet& set, uint32_t n_obj, const ShadeParams& p, const float* depth, float* dst,
                  uint64_t* counters);
+int launch_pyramid_fused(Ctx* c, const SphereSet& spheres, uint32_t n_obj, const PyramidParams& fp);
 int launch_detile(Ctx* c, const float* tiles, uint32_t n_ranks, uint32_t tiles_per_rank, float* rgb);
 int launch_to_rgba8(Ctx* c, const float* rgb, uint8_t* rgba, uint64_t n_pixels);
 

@@ -22,23 +22,47 @@ def oracle_scene(scene):
     return O.scene_from_bytes(bytes(scene))
 
 
+def on_screen_mask(shape, level, count, w, h):
+    """Texels of pyramid level `level` that have a descendant inside the w x h frame.  The fused pyramid
+    kernel (rt_config.fuse_levels = 1) computes exactly these; the others are never read
+    by anything (the reference computes them only because its images are padded to multiples of 8)."""
+    s = count - 1 - level
+    gy, gx = np.mgrid[0:shape[0], 0:shape[1]]
+    return ((gx << s) < w) & ((gy << s) < h)
+
+
+def set_fused(r, fused):
+    cfg = r.default_config()
+    cfg.fuse_levels = int(fused)
+    r.set_config(cfg)
+
+
 def check_frame(r, scene, w, h, rot=(0, 0, 0, 1), pos=(0, 0, 0), levels=True):
+    """Both launch schedules against oracle A: one launch per level + shade (the reference's own
+    schedule; every texel compared) and the fused one-launch pyramid (texels with on-screen descendants)."""
     r.set_scene(scene)
     r.resize(w, h)
-    rgb, depth = r.render(rot, pos, want_depth=True)
     ref = O.render_a(oracle_scene(scene), w, h, rot=rot, pos=pos)
     assert r.level_info() == [lv.shape[::-1] for lv in ref["levels"]]
-    if levels:
-        for i, lv in enumerate(ref["levels"]):
-            got = r.read_level(i)
-            assert np.array_equal(got, lv), f"level {i}: {np.count_nonzero(got != lv)} texels differ"
-    assert np.array_equal(depth, ref["levels"][-1])
-    err = np.abs(rgb - ref["rgb"]).max()
-    assert err <= RGB_TOL, err
-    st = r.stats()
-    assert st["hit_pixels"] == ref["counters"]["hit_pixels"]
-    assert st["shadow_rays"] == ref["counters"]["shadow_rays"]
-    assert st["primary_rays"] == w * h
+    count = len(ref["levels"])
+    try:
+        for fused in (False, True):
+            set_fused(r, fused)
+            rgb, depth = r.render(rot, pos, want_depth=True)
+            if levels:
+                for i, lv in enumerate(ref["levels"]):
+                    got = r.read_level(i)
+                    m = on_screen_mask(lv.shape, i, count, w, h) if fused else np.ones(lv.shape, bool)
+                    assert np.array_equal(got[m], lv[m]), f"fused={fused} level {i}: {np.count_nonzero(got[m] != lv[m])} texels differ"
+            assert np.array_equal(depth[:h, :w], ref["levels"][-1][:h, :w])
+            err = np.abs(rgb - ref["rgb"]).max()
+            assert err <= RGB_TOL, (fused, err)
+            st = r.stats()
+            assert st["hit_pixels"] == ref["counters"]["hit_pixels"]
+            assert st["shadow_rays"] == ref["counters"]["shadow_rays"]
+            assert st["primary_rays"] == w * h
+    finally:
+        set_fused(r, False)
     return rgb, ref
 
 
@@ -62,10 +86,18 @@ def test_against_committed_fixture(renderer, golden_dir, name):
     renderer.set_scene(g["scene"].tobytes())
     w, h = int(g["width"]), int(g["height"])
     renderer.resize(w, h)
-    rgb = renderer.render(g["rot"], g["pos"])
-    for i in range(len(renderer.level_info())):
-        assert np.array_equal(renderer.read_level(i), g[f"level{i}"])
-    assert np.abs(rgb - g["rgb"]).max() <= RGB_TOL
+    count = len(renderer.level_info())
+    try:
+        for fused in (False, True):
+            set_fused(renderer, fused)
+            rgb = renderer.render(g["rot"], g["pos"])
+            for i in range(count):
+                got, want = renderer.read_level(i), g[f"level{i}"]
+                m = on_screen_mask(want.shape, i, count, w, h) if fused else np.ones(want.shape, bool)
+                assert np.array_equal(got[m], want[m])
+            assert np.abs(rgb - g["rgb"]).max() <= RGB_TOL
+    finally:
+        set_fused(renderer, False)
 
 
 @pytest.mark.parametrize("n_obj,n_light", [(1, 0), (1, 1), (2, 3), (3, 1), (5, 2), (6, 1), (7, 8), (8, 8)])
@@ -88,19 +120,20 @@ def test_camera_inside_sphere_and_all_miss(renderer):
 
 
 def test_config_is_honoured(renderer):
-    cfg = renderer.default_config()
-    cfg.render_dist, cfg.cam_fall_off, cfg.light_fall_off, cfg.ray_radius = 40.0, 0.02, 0.005, 0.02
-    renderer.set_config(cfg)
     try:
         scene = R.default_scene()
         renderer.set_scene(scene)
         renderer.resize(96, 64)
-        rgb, depth = renderer.render(want_depth=True)
         ocfg = O.default_config()
         ocfg.render_dist, ocfg.cam_fall_off, ocfg.light_fall_off, ocfg.ray_radius = 40.0, 0.02, 0.005, 0.02
         ref = O.render_a(oracle_scene(scene), 96, 64, cfg=ocfg)
-        assert np.array_equal(depth, ref["levels"][-1])
-        assert np.abs(rgb - ref["rgb"]).max() <= RGB_TOL
+        for fused in (0, 1):
+            cfg = renderer.default_config()
+            cfg.render_dist, cfg.cam_fall_off, cfg.light_fall_off, cfg.ray_radius, cfg.fuse_levels = 40.0, 0.02, 0.005, 0.02, fused
+            renderer.set_config(cfg)
+            rgb, depth = renderer.render(want_depth=True)
+            assert np.array_equal(depth, ref["levels"][-1])
+            assert np.abs(rgb - ref["rgb"]).max() <= RGB_TOL
     finally:
         renderer.set_config(renderer.default_config())
 
