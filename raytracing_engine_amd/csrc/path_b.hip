@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, P
 constexpr int kTrisPerRound = 2;
 
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(256) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
                                                 const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
                                                 unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min) {
     extern __shared__ unsigned long long lds_stack[];  // sk.lds_cap x 256 entries

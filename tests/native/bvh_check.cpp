@@ -1,0 +1,97 @@
+// bvh_check.cpp — host-side structural check of the compressed 8-wide BVH (csrc/bvh_build.cpp),
+// built with -fsanitize=address,undefined by tests/test_bvh_build_host.py.  No GPU involved.
+//   bvh_check <n_tris> <seed> <edge>
+// Verifies: the leaf order is a permutation; every triangle is reachable exactly once; inner-child
+// indexing (child_base + popcount(imask below slot)) and leaf encoding (unary count, offset < 24) are
+// consistent; every leaf triangle lies inside its de-quantised child box; depth <= stack_need - 1.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../raytracing_engine_amd/csrc/bvh_build.h"
+
+static uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+int main(int argc, char** argv) {
+    const uint32_t n = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 1000;
+    const uint32_t seed = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 1;
+    const float edge = argc > 3 ? (float)std::atof(argv[3]) : 0.5f;
+    std::vector<float> v0(3 * (size_t)n), e1(3 * (size_t)n), e2(3 * (size_t)n);
+    uint32_t s = hash32(seed);
+    auto u = [&]() { s = hash32(s + 0x9e3779b9u); return (float)(s >> 8) * 0x1p-24f; };
+    for (size_t i = 0; i < (size_t)n * 3; i++) {
+        v0[i] = u() * 20.0f - 10.0f;
+        e1[i] = (u() * 2.0f - 1.0f) * edge;
+        e2[i] = (u() * 2.0f - 1.0f) * edge;
+    }
+    if (n > 10) {  // degenerate and duplicate triangles must survive
+        for (int a = 0; a < 3; a++) e1[3 * 5 + a] = e2[3 * 5 + a] = 0.0f;
+        for (int a = 0; a < 3; a++) { v0[3 * 7 + a] = v0[3 * 6 + a]; e1[3 * 7 + a] = e1[3 * 6 + a]; e2[3 * 7 + a] = e2[3 * 6 + a]; }
+    }
+    rt::BvhResult b;
+    if (!rt::build_bvh(v0.data(), e1.data(), e2.data(), n, rt::kBvhMaxDepth, &b)) { std::puts("FAIL build"); return 1; }
+    if (b.order.size() != n || b.nodes.size() != (size_t)b.n_nodes * 20) { std::puts("FAIL sizes"); return 1; }
+    std::vector<uint8_t> seen(n, 0);
+    for (uint32_t t : b.order) {
+        if (t >= n || seen[t]) { std::puts("FAIL order is not a permutation"); return 1; }
+        seen[t] = 1;
+    }
+    std::vector<uint32_t> reached(n, 0);
+    struct Item { uint32_t node, level; };
+    std::vector<Item> stack{{0, 1}};
+    uint32_t max_level = 0, n_visited = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        if (it.node >= b.n_nodes) { std::puts("FAIL node index out of range"); return 1; }
+        n_visited++;
+        max_level = it.level > max_level ? it.level : max_level;
+        const uint32_t* w = &b.nodes[(size_t)it.node * 20];
+        float p[3];
+        std::memcpy(p, w, 12);
+        float scale[3];
+        for (int a = 0; a < 3; a++) { const uint32_t bits = ((w[3] >> (8 * a)) & 0xffu) << 23; std::memcpy(&scale[a], &bits, 4); }
+        const uint32_t imask = w[3] >> 24, child_base = w[4], tri_base = w[5];
+        const uint8_t* meta = reinterpret_cast<const uint8_t*>(&w[6]);
+        const uint8_t* q = reinterpret_cast<const uint8_t*>(&w[8]);  // [6][8]
+        for (int slot = 0; slot < 8; slot++) {
+            const uint32_t m = meta[slot];
+            const bool inner = (imask >> slot) & 1u;
+            if (m == 0) { if (inner) { std::puts("FAIL empty slot flagged inner"); return 1; } continue; }
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; a++) { lo[a] = p[a] + (float)q[a * 8 + slot] * scale[a]; hi[a] = p[a] + (float)q[(3 + a) * 8 + slot] * scale[a]; }
+            if (inner) {
+                if ((m >> 5) != 1u || (m & 31u) != 24u + (uint32_t)slot) { std::puts("FAIL inner meta"); return 1; }
+                const uint32_t rel = (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u));
+                stack.push_back({child_base + rel, it.level + 1});
+            } else {
+                const uint32_t bits = m >> 5, off = m & 31u;
+                const uint32_t cnt = bits == 1 ? 1 : bits == 3 ? 2 : bits == 7 ? 3 : 0;
+                if (!cnt || off + cnt > 24) { std::puts("FAIL leaf meta"); return 1; }
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const uint32_t li = tri_base + off + k;
+                    if (li >= n) { std::puts("FAIL leaf triangle index"); return 1; }
+                    const uint32_t t = b.order[li];
+                    reached[t]++;
+                    for (int a = 0; a < 3; a++) {
+                        const float x0 = v0[3 * (size_t)t + a], x1 = x0 + e1[3 * (size_t)t + a], x2 = x0 + e2[3 * (size_t)t + a];
+                        const float mn = std::fmin(x0, std::fmin(x1, x2)), mx = std::fmax(x0, std::fmax(x1, x2));
+                        if (mn < lo[a] || mx > hi[a]) { std::printf("FAIL triangle %u outside its leaf box on axis %d\n", t, a); return 1; }
+                    }
+                }
+            }
+        }
+    }
+    for (uint32_t t = 0; t < n; t++)
+        if (reached[t] != 1) { std::printf("FAIL triangle %u reached %u times\n", t, reached[t]); return 1; }
+    if (n_visited != b.n_nodes) { std::puts("FAIL unreachable nodes"); return 1; }
+    if (max_level != b.depth || b.stack_need != b.depth + 1) { std::printf("FAIL depth %u vs %u\n", max_level, b.depth); return 1; }
+    std::printf("OK n=%u nodes=%u depth=%u tris/node=%.2f\n", n, b.n_nodes, b.depth, (double)n / b.n_nodes);
+    return 0;
+}

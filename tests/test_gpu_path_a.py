@@ -244,3 +244,27 @@ def test_full_hd_parity_and_properties(renderer):
     up = np.repeat(np.repeat(parent, 2, 0), 2, 1)[:1080, :1920]
     thr = np.float32(1.4142135 * 8.0) / np.float32(1920)
     assert (depth >= up - thr * 1.001).all()
+
+
+@pytest.mark.parametrize("w,h", [(8, 8), (12, 10), (17, 9), (2048, 64)])
+def test_tiny_and_wide_views(renderer, w, h):
+    """Width < 16 gives a single pyramid level (src/main.rs:639); 2048 is the widest view the
+    reference's 9-image array supports (shaders/compute.glsl:14-15)."""
+    check_frame(renderer, R.default_scene(), w, h)
+
+
+def test_4k_nine_levels(renderer):
+    """BASELINE.json configs[4] resolution on path A: 3840x2160 = 9 levels, the cap of
+    COMPUTE_IMAGE_COUNT (src/main.rs:359); full-frame comparison against the oracle."""
+    rgb, ref = check_frame(renderer, R.cornell_scene(), 3840, 2160, levels=False)
+    assert len(renderer.level_info()) == 9 and renderer.level_info()[-1] == (3840, 2160)
+
+
+def test_resize_and_rescene_cycles(renderer):
+    """Re-allocation paths: many resizes and scene swaps must keep giving oracle-identical frames."""
+    for w, h, scene in [(64, 64, R.default_scene()), (640, 360, R.cornell_scene()), (96, 64, R.default_scene()), (640, 360, R.cornell_scene())]:
+        renderer.set_scene(scene)
+        renderer.resize(w, h)
+        rgb, depth = renderer.render(want_depth=True)
+        ref = O.render_a(oracle_scene(scene), w, h)
+        assert np.array_equal(depth, ref["levels"][-1]) and np.abs(rgb - ref["rgb"]).max() <= RGB_TOL

@@ -188,3 +188,26 @@ def test_full_hd_properties(renderer):
     # just rows 520..536 of the 1920x1080 frame and must reproduce those rows of the GPU frame exactly
     band, _ = O.TriScene(v, a, e).render(1920, 1080, spp=4, bounces=1, seed=1, sky=(0.2, 0.2, 0.25), rows=(520, 536))
     assert np.array_equal(a1[520:536], band)
+
+
+def test_deep_paths_and_many_samples(renderer):
+    """Maximum bounce count (15) and a large spp on a small view."""
+    check_pt(renderer, scenes.cornell_tri_scene(), 24, 24, pos=(0, 1, 0), spp=1, bounces=15, seed=4)
+    check_pt(renderer, scenes.cornell_tri_scene(), 16, 16, pos=(0, 1, 0), spp=64, bounces=1, seed=6)
+
+
+def test_mesh_swaps(renderer):
+    """rt_set_mesh replaces mesh, BVH and lights; frames follow."""
+    for mesh, pos in [(scenes.cornell_tri_scene(), (0, 1, 0)), (scenes.soup_scene(3000, seed=5, edge=1.0), (0, 0, 0)), (scenes.cornell_tri_scene(), (0, 1, 0))]:
+        check_pt(renderer, mesh, 64, 48, pos=pos, spp=2, bounces=1, seed=2, sky=(0.1, 0.1, 0.1))
+
+
+def test_shadow_overlap_does_not_change_results(renderer):
+    """The shadow kernel runs beside the next closest-hit kernel by default; serialised it must give
+    the same frame (per-path sums keep their order)."""
+    v, a, e = scenes.cornell_tri_scene()
+    renderer.set_mesh(v, a, e)
+    renderer.resize(96, 96)
+    one = renderer.render_pt(pos=(0, 1, 0), spp=3, bounces=3, seed=8)
+    two = renderer.render_pt(pos=(0, 1, 0), spp=3, bounces=3, seed=8, tune_no_overlap=1)
+    assert np.array_equal(one, two)
