@@ -148,6 +148,20 @@ int rt_render_device(rt_ctx* ctx, const float rot[4], const float pos[3], uint32
 int rt_detile_device(rt_ctx* ctx, const void* tiles_dev, uint32_t n_ranks, uint32_t tiles_per_rank, void* rgb_dev);
 int rt_synchronize(rt_ctx* ctx);
 
+/* The exchange step for hosts without a communication library of their own (no reference
+ * counterpart: the reference drives one GPU, src/main.rs:448-460).  One process per GPU:
+ * rank 0 calls rt_comm_unique_id and hands the 128 bytes to every rank (file, socket, MPI...);
+ * every rank calls rt_comm_init (collective; it also sets the framebuffer partition to rank/n_ranks);
+ * after rendering tile-major, every rank calls rt_gather_tiles: the tiles go to rank 0 over RCCL
+ * (grouped ncclSend/ncclRecv, one direct xGMI link per peer) on the context's stream, into
+ * gathered_dev[rank][tiles_per_rank][64][64][3] on rank 0 (ignored elsewhere); rt_detile_device then
+ * scatters them into the frame.  RCCL is loaded on first use. */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]);
+int rt_comm_init(rt_ctx* ctx, const uint8_t id[RT_COMM_ID_BYTES], uint32_t rank, uint32_t n_ranks);
+int rt_gather_tiles(rt_ctx* ctx, const void* tiles_dev, void* gathered_dev, uint32_t tiles_per_rank);
+int rt_comm_destroy(rt_ctx* ctx);
+
 /* Test hook: copy pyramid level `level` of the last frame to host. */
 int rt_read_level(rt_ctx* ctx, uint32_t level, float* out, uint32_t* w, uint32_t* h);
 /* Last frame as a *_UNORM swapchain would hold it (src/main.rs:471-486): linear, clamped,

@@ -105,6 +105,10 @@ PROTOTYPES = {
     "rt_render_device": (C.c_int, [_vp, _fp, _fp, C.c_uint32, _vp, C.c_int]),
     "rt_detile_device": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
     "rt_synchronize": (C.c_int, [_vp]),
+    "rt_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "rt_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]),
+    "rt_gather_tiles": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
+    "rt_comm_destroy": (C.c_int, [_vp]),
     "rt_read_level": (C.c_int, [_vp, C.c_uint32, _fp, _u32p, _u32p]),
     "rt_read_rgba8": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
     "rt_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),

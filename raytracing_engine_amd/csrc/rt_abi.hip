@@ -330,6 +330,7 @@ void rt_destroy(rt_ctx* ctx) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    rt::comm_free(c);
     free_frame(c);
     rt::pt_free(c);
     if (c->d_counters) (void)hipFree(c->d_counters);

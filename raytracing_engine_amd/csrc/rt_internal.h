@@ -183,6 +183,8 @@ struct Ctx {
     bool frame_valid = false;
     PtData pt;
     int n_cus = 256;
+    void* comm = nullptr;  // ncclComm_t once rt_comm_init ran (rt_abi_comm.hip)
+    uint32_t comm_rank = 0, comm_ranks = 1;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -220,5 +222,6 @@ int launch_pt_resolve(Ctx* c, const PtFrame& f, const PtState& st, float* acc, f
 int launch_pt_trace_rays(Ctx* c, const PtScene& sc, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out,
                          int* tri_out, const StackCfg& sk, uint32_t grid);
 void pt_free(Ctx* c);
+void comm_free(Ctx* c);  // rt_abi_comm.hip
 
 }  // namespace rt

@@ -217,6 +217,25 @@ class Renderer:
     def synchronize(self):
         self._check(self._lib.rt_synchronize(self._ctx))
 
+    # ---- native RCCL exchange (for hosts without torch.distributed) ---------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = _lib.load().rt_comm_unique_id(buf)
+        if rc != 0:
+            raise RtError(rc, "rt_comm_unique_id failed (librccl.so not loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, n_ranks):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.rt_comm_init(self._ctx, buf, rank, n_ranks))
+
+    def gather_tiles(self, tiles_ptr, gathered_ptr, tiles_per_rank):
+        self._check(self._lib.rt_gather_tiles(self._ctx, C.c_void_p(tiles_ptr), C.c_void_p(gathered_ptr), tiles_per_rank))
+
+    def comm_destroy(self):
+        self._check(self._lib.rt_comm_destroy(self._ctx))
+
     def read_level(self, level):
         w, h = C.c_uint32(), C.c_uint32()
         self._check(self._lib.rt_read_level(self._ctx, level, None, C.byref(w), C.byref(h)))

@@ -28,7 +28,7 @@ def declared_functions():
 def test_library_exports_every_declared_symbol():
     lib = R.load()
     names = declared_functions()
-    assert len(names) >= 28 and "rt_render" in names and "rt_render_pt" in names
+    assert len(names) >= 32 and "rt_render" in names and "rt_render_pt" in names
     for n in names:
         assert hasattr(lib, n), f"librt_amd.so does not export {n}"
         assert n in _lib.PROTOTYPES, f"python binding lacks a prototype for {n}"
