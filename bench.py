@@ -271,7 +271,30 @@ class TriWorkload:
                           f"median-split BVH (OpenMP, {threads} threads), {rays} rays in {dt:.2f} s"}
 
 
-WORKLOADS = {SpheresWorkload.name: SpheresWorkload, TriWorkload.name: TriWorkload}
+class TerrainWorkload(TriWorkload):
+    """Context workload, not a BASELINE config: 1 M triangles forming a closed height-field surface (rays
+    end at their first hit) with the same camera model, resolution, spp and bounce count."""
+
+    name = "terrain1m_1080p_4spp"
+
+    def __init__(self, R, renderer):
+        self.R, self.r = R, renderer
+        self.mesh = R.scenes.terrain_scene(708, seed=1)
+        self.n_tris = len(self.mesh[0])
+        self.rot = R.camera_quat(0.0, -0.25)
+        self.pos = np.array([0, 0, 4], np.float32)
+        self.sky = (0.4, 0.5, 0.7)
+        renderer.set_mesh(*self.mesh)
+        renderer.resize(self.width, self.height)
+        self.params = renderer.pt_params(spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky)
+
+    def describe(self):
+        d = super().describe()
+        d["workload"] = d["workload"].replace(f"random triangles (edge +-{self.edge})", "height-field triangles (708x708 cells)")
+        return d
+
+
+WORKLOADS = {SpheresWorkload.name: SpheresWorkload, TriWorkload.name: TriWorkload, TerrainWorkload.name: TerrainWorkload}
 
 
 def main():

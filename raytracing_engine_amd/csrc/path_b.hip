@@ -347,7 +347,8 @@ __global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, P
 // ballot + prefix-popcount to assign entries).  The wave exits when the queue is drained and all its
 // lanes are done, so the grid is sized for the machine, not for the queue length.
 // Between two refill checks every lane visits one node and tests up to `kTrisPerRound` triangles.
-constexpr int kTrisPerRound = 2;
+constexpr int kTrisPerRound = 1;
+constexpr uint32_t kReserveMax = 256;  // largest queue range one atomic reserves for a wave
 
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
@@ -369,6 +370,10 @@ __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st,
     uint32_t slot = 0;  // closest: path id; any-hit: shadow-queue index
     bool has_ray = false, occluded = false;
     bool exhausted = n == 0;  // wave-uniform
+    bool queue_dry = n == 0;  // wave-uniform: the shared head has passed the end of the queue
+    uint32_t resv_next = 0, resv_end = 0, resv_size = 0;  // wave-uniform: private reservation and its adaptive size
+    uint32_t rounds_since_atomic = 1000u;                 // wave-uniform
+    uint32_t rounds = 0, alive_rounds = 0;                // COUNT only
     bool alive = false;       // this lane still has traversal work for its ray
 
     for (;;) {
@@ -391,34 +396,60 @@ __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st,
                 has_ray = false;
             }
             if (!exhausted) {
-                const uint32_t want = (uint32_t)__popcll(idle);
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, want);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (!alive) {
-                    const uint32_t i = base + (uint32_t)__popcll(idle & lt_mask);
-                    if (i < n) {
-                        if (ANY) {
-                            const float4 so = st.sh_o[i], sd = st.sh_d[i];
-                            r = make_tray(mk(so.x, so.y, so.z), mk(sd.x, sd.y, sd.z), kShadowTmax);
-                            slot = i;
-                            occluded = false;
-                        } else {
-                            slot = queue[i];
-                            const float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
-                            r = make_tray(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), __builtin_inff());
-                            best = Hit{__builtin_inff(), -1, 0xffffffffu};
-                        }
-                        has_ray = true;
-                        alive = true;
-                        G = root_group();
-                        T = Group{0u, 0u};
-                        stk.sp = 0;
-                    }
+                // Entries come from a wave-private reservation topped up by one returning atomic on the
+                // shared head.  That word answers only ~90 atomics per microsecond chip-wide, which at
+                // one atomic per 32-ray refill caps the whole chip near 3 Grays/s - a real limit when
+                // rays are short (closed surfaces).  So the reservation ADAPTS: when refills come
+                // within a few rounds of each other (short rays) it doubles up to kReserveMax; when
+                // they are far apart (long rays) it takes exactly what the idle lanes need, because
+                // then the width of the window of rays in flight decides the L2 hit rate instead.
+                uint32_t want = (uint32_t)__popcll(idle);
+                const uint32_t my_rank = (uint32_t)__popcll(idle & lt_mask);
+                uint32_t i = n;  // n = nothing for this lane
+                const uint32_t avail = resv_end - resv_next, take0 = want < avail ? want : avail;
+                if (my_rank < take0) i = resv_next + my_rank;
+                resv_next += take0;
+                want -= take0;
+                if (want > 0 && !queue_dry) {
+                    if (rounds_since_atomic < 8u) resv_size = resv_size ? (resv_size * 2u > kReserveMax ? kReserveMax : resv_size * 2u) : 64u;
+                    else if (rounds_since_atomic > 24u) resv_size = 0u;
+                    rounds_since_atomic = 0u;
+                    const uint32_t size = want > resv_size ? want : resv_size;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(head, size);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const uint32_t end = base + size < n ? base + size : n;
+                    if (my_rank >= take0 && base + (my_rank - take0) < end) i = base + (my_rank - take0);
+                    resv_next = base + want < end ? base + want : end;
+                    resv_end = end;
+                    queue_dry = base + size >= n;
                 }
-                exhausted = base + want >= n;
+                exhausted = queue_dry && resv_next >= resv_end;
+                if (!alive && i < n) {
+                    if (ANY) {
+                        const float4 so = st.sh_o[i], sd = st.sh_d[i];
+                        r = make_tray(mk(so.x, so.y, so.z), mk(sd.x, sd.y, sd.z), kShadowTmax);
+                        slot = i;
+                        occluded = false;
+                    } else {
+                        slot = queue[i];
+                        const float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
+                        r = make_tray(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), __builtin_inff());
+                        best = Hit{__builtin_inff(), -1, 0xffffffffu};
+                    }
+                    has_ray = true;
+                    alive = true;
+                    G = root_group();
+                    T = Group{0u, 0u};
+                    stk.sp = 0;
+                }
             }
             if (__ballot(alive) == 0ull) break;  // queue drained and every lane retired
+        }
+        rounds_since_atomic++;
+        if (COUNT) {  // occupancy of the round: wave-rounds and alive lane-rounds
+            rounds++;
+            alive_rounds += (uint32_t)__popcll(__ballot(alive));
         }
         // node phase: lanes without pending triangles visit their next node
         if (alive && T.y == 0u) {
@@ -447,6 +478,10 @@ __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st,
             b += __shfl_down(b, off);
         }
         if (lane == 0) {
+            if (!ANY) {
+                atomicAdd(&stats[6], (unsigned long long)rounds);
+                atomicAdd(&stats[7], (unsigned long long)alive_rounds);
+            }
             atomicAdd(&stats[ANY ? 4 : 0], a);
             atomicAdd(&stats[ANY ? 5 : 1], b);
         }

@@ -295,6 +295,8 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         pt.stats.tris_tested = st[1];
         pt.stats.shadow_nodes_visited = st[4];
         pt.stats.shadow_tris_tested = st[5];
+        pt.stats.wave_rounds = st[6];
+        pt.stats.alive_lane_rounds = st[7];
         pt.stats.stack_overflow = (uint32_t)st[2];
         RT_HIP(c, hipEventElapsedTime(&pt.stats.ms_total, c->ev_begin, c->ev_end));
         float sums[5] = {};

@@ -81,3 +81,44 @@ def cornell_tri_scene():
     box(-2.5, 14, -3.0, 1.8, 1.8, 3.0, (0.7, 0.7, 0.3))
     box(2.5, 10, -4.5, 1.5, 1.5, 1.5, (0.3, 0.5, 0.8))
     return np.array(tris, f), np.array(alb, f), np.array(emi, f)
+
+
+def terrain_scene(grid=708, seed=1, light_emission=(6.0, 6.0, 6.0)):
+    """A closed-surface scene for context (the soup is a participating-medium-like worst case): a
+    height field of grid x grid cells = 2*grid^2 triangles over x in [-30,30], y in [2,62] (the camera at
+    the origin looks along +Y and slightly down onto it), heights from three octaves of hashed value
+    noise, plus the same emissive quad overhead.  grid=708 gives 1 002 528 + 2 triangles."""
+    f = np.float32
+    n = int(grid)
+
+    def lattice(cells, stream):
+        return _uniform(seed, stream, (cells + 1) * (cells + 1)).reshape(cells + 1, cells + 1)
+
+    def value_noise(cells, stream):
+        lat = lattice(cells, stream)
+        t = np.linspace(0, cells, n + 1, dtype=np.float64)
+        i = np.minimum(t.astype(np.int64), cells - 1)
+        fr = (t - i)
+        fr = fr * fr * (3 - 2 * fr)
+        a = lat[i][:, i] * (1 - fr)[None, :] + lat[i][:, i + 1] * fr[None, :]
+        b = lat[i + 1][:, i] * (1 - fr)[None, :] + lat[i + 1][:, i + 1] * fr[None, :]
+        return a * (1 - fr)[:, None] + b * fr[:, None]
+
+    hgt = (6.0 * value_noise(6, 20) + 2.0 * value_noise(24, 21) + 0.5 * value_noise(96, 22)).astype(f) - f(9.0)
+    xs = np.linspace(-30, 30, n + 1, dtype=f)
+    ys = np.linspace(2, 62, n + 1, dtype=f)
+    X, Y = np.meshgrid(xs, ys)
+    P = np.stack([X, Y, hgt], -1)  # (n+1, n+1, 3)
+    p00, p10, p01, p11 = P[:-1, :-1], P[:-1, 1:], P[1:, :-1], P[1:, 1:]
+    t1 = np.concatenate([p00, p10, p11], -1).reshape(-1, 9)
+    t2 = np.concatenate([p00, p11, p01], -1).reshape(-1, 9)
+    verts = np.concatenate([t1, t2]).astype(f)
+    m = len(verts)
+    u = [_uniform(seed, 30 + k, m) for k in range(3)]
+    albedo = (np.stack(u, 1) * f(0.4) + f(0.4)).astype(f)
+    emission = np.zeros((m, 3), f)
+    quad = _quad(np.array([-6, 20, 14], f), np.array([6, 20, 14], f), np.array([6, 32, 14], f), np.array([-6, 32, 14], f))
+    verts = np.concatenate([verts, np.array(quad, f)])
+    albedo = np.concatenate([albedo, np.zeros((2, 3), f)])
+    emission = np.concatenate([emission, np.tile(np.asarray(light_emission, f), (2, 1))])
+    return verts, albedo, emission
