@@ -185,7 +185,7 @@ typedef struct rt_pt_params {
     float ray_eps;     /* origin offset along the shading normal (default 1e-3) */
     uint32_t count_traversal; /* 1: count BVH nodes fetched / triangles tested (rt_pt_stats) */
     uint32_t max_paths;       /* cap on paths in flight per pass (0 = default 2^25); spp is split into passes */
-    uint32_t tune_refill_min;    /* tuning: idle lanes per wave that trigger a refill (0 = default 16) */
+    uint32_t tune_refill_min;    /* tuning: idle lanes per wave that trigger a refill (0 = default 24; byte 1: triangle tests per round, 0 = 1) */
     uint32_t tune_blocks_per_cu; /* tuning: persistent workgroups per CU (0 = as many as the LDS stacks allow) */
     uint32_t tune_lds_stack;     /* tuning: traversal-stack entries kept in LDS per lane (0 = default 8), rest spills */
     uint32_t tune_no_overlap;    /* tuning: 1 = keep the shadow kernel on the main stream (no overlap with the next closest-hit kernel) */

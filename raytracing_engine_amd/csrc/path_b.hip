@@ -343,12 +343,12 @@ __global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, P
 // Persistent waves with per-lane refill.  Traversal lengths are heavy-tailed (a ray may end after 3
 // nodes or after 500), so a wave that waits for its slowest ray idles most lanes.  Instead every
 // lane carries its own ray: whenever at least `refill_min` lanes have finished, the wave retires
-// their results and hands them the next rays of the device-resident queue (one atomic per refill,
-// ballot + prefix-popcount to assign entries).  The wave exits when the queue is drained and all its
+// their results and hands them the next rays of the device-resident queue (one atomic per refill on
+// one of PT_HEADS interleaved stream heads, ballot + prefix-popcount to assign entries; a wave whose
+// stream runs dry moves on to the next one, so the tail of the queue is shared by all waves).  The wave exits when the queue is drained and all its
 // lanes are done, so the grid is sized for the machine, not for the queue length.
 // Between two refill checks every lane visits one node and tests up to `kTrisPerRound` triangles.
 constexpr int kTrisPerRound = 1;
-constexpr uint32_t kReserveMax = 256;  // largest queue range one atomic reserves for a wave
 
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st,
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t n = *count_ptr;
-    const int tris_per_round = (int)(refill_min >> 8) ? (int)(refill_min >> 8) : kTrisPerRound;
+    const int tris_per_round = (int)((refill_min >> 8) & 0xffu) ? (int)((refill_min >> 8) & 0xffu) : kTrisPerRound;
     refill_min &= 0xffu;
     TravCounters tc{0, 0, 0};
 
@@ -369,10 +369,9 @@ __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st,
     Group G{0u, 0u}, T{0u, 0u};
     uint32_t slot = 0;  // closest: path id; any-hit: shadow-queue index
     bool has_ray = false, occluded = false;
-    bool exhausted = n == 0;  // wave-uniform
-    bool queue_dry = n == 0;  // wave-uniform: the shared head has passed the end of the queue
-    uint32_t resv_next = 0, resv_end = 0, resv_size = 0;  // wave-uniform: private reservation and its adaptive size
-    uint32_t rounds_since_atomic = 1000u;                 // wave-uniform
+    bool exhausted = n == 0;  // wave-uniform: every stream of the queue has been found dry
+    uint32_t stream = (blockIdx.x * 4u + (threadIdx.x >> 6)) & (PT_HEADS - 1u);  // wave-uniform: the stream this wave pulls from
+    uint32_t dry_streams = 0;                                                    // wave-uniform
     uint32_t rounds = 0, alive_rounds = 0;                // COUNT only
     bool alive = false;       // this lane still has traversal work for its ray
 
@@ -396,35 +395,19 @@ __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st,
                 has_ray = false;
             }
             if (!exhausted) {
-                // Entries come from a wave-private reservation topped up by one returning atomic on the
-                // shared head.  That word answers only ~90 atomics per microsecond chip-wide, which at
-                // one atomic per 32-ray refill caps the whole chip near 3 Grays/s - a real limit when
-                // rays are short (closed surfaces).  So the reservation ADAPTS: when refills come
-                // within a few rounds of each other (short rays) it doubles up to kReserveMax; when
-                // they are far apart (long rays) it takes exactly what the idle lanes need, because
-                // then the width of the window of rays in flight decides the L2 hit rate instead.
-                uint32_t want = (uint32_t)__popcll(idle);
+                // One returning atomic on the wave's stream head reserves exactly what the idle lanes
+                // need.  Stream-local entry j of stream k is queue entry ((j / 64) * PT_HEADS + k) * 64 + j % 64.
+                const uint32_t want = (uint32_t)__popcll(idle);
                 const uint32_t my_rank = (uint32_t)__popcll(idle & lt_mask);
-                uint32_t i = n;  // n = nothing for this lane
-                const uint32_t avail = resv_end - resv_next, take0 = want < avail ? want : avail;
-                if (my_rank < take0) i = resv_next + my_rank;
-                resv_next += take0;
-                want -= take0;
-                if (want > 0 && !queue_dry) {
-                    if (rounds_since_atomic < 8u) resv_size = resv_size ? (resv_size * 2u > kReserveMax ? kReserveMax : resv_size * 2u) : 64u;
-                    else if (rounds_since_atomic > 24u) resv_size = 0u;
-                    rounds_since_atomic = 0u;
-                    const uint32_t size = want > resv_size ? want : resv_size;
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(head, size);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const uint32_t end = base + size < n ? base + size : n;
-                    if (my_rank >= take0 && base + (my_rank - take0) < end) i = base + (my_rank - take0);
-                    resv_next = base + want < end ? base + want : end;
-                    resv_end = end;
-                    queue_dry = base + size >= n;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head + stream * PT_HEAD_STRIDE, want);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t j = base + my_rank, je = base + want;
+                const uint32_t i = !alive ? ((((j >> 6) * PT_HEADS + stream) << 6) | (j & 63u)) : n;  // >= n: nothing for this lane
+                if (((((je >> 6) * PT_HEADS + stream) << 6) | (je & 63u)) >= n) {  // this stream is dry (entries grow with j): move on
+                    stream = (stream + 1u) & (PT_HEADS - 1u);
+                    exhausted = ++dry_streams >= PT_HEADS;
                 }
-                exhausted = queue_dry && resv_next >= resv_end;
                 if (!alive && i < n) {
                     if (ANY) {
                         const float4 so = st.sh_o[i], sd = st.sh_d[i];
@@ -446,7 +429,6 @@ __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st,
             }
             if (__ballot(alive) == 0ull) break;  // queue drained and every lane retired
         }
-        rounds_since_atomic++;
         if (COUNT) {  // occupancy of the round: wave-rounds and alive lane-rounds
             rounds++;
             alive_rounds += (uint32_t)__popcll(__ballot(alive));

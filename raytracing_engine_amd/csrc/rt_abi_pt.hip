@@ -177,7 +177,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     uint32_t grid_persistent = 0;
     if (int rc = stack_config(c, prm->tune_lds_stack, prm->tune_blocks_per_cu, &stack_cap, &grid_persistent)) return rc;
     // low byte: idle lanes that trigger a refill; next byte (tuning): inner steps per round
-    const uint32_t refill_min = (prm->tune_refill_min & 0xffu ? std::min<uint32_t>(prm->tune_refill_min & 0xffu, 64u) : 32u) | (prm->tune_refill_min & 0xff00u);
+    const uint32_t refill_min = (prm->tune_refill_min & 0xffu ? std::min<uint32_t>(prm->tune_refill_min & 0xffu, 64u) : 24u) | (prm->tune_refill_min & 0xff00u);
     const uint32_t grid_stride = (uint32_t)c->n_cus * 2u;  // 1024-thread workgroups, grid-stride
 
     static thread_local std::vector<hipEvent_t> ev_pool;

@@ -89,7 +89,20 @@ struct PyramidParams {
 };
 
 // ---- path B (triangles + BVH + path tracing) -------------------------------------
-enum { PT_CTR_COUNT = 0, PT_CTR_SHADOW_COUNT = 1, PT_CTR_HEAD_CLOSEST = 2, PT_CTR_HEAD_SHADOW = 3, PT_CTR_STRIDE = 4 };
+// Per-depth counter block.  The ray queues are consumed through PT_HEADS interleaved streams: stream k
+// owns the 64-entry blocks k, k + PT_HEADS, k + 2 PT_HEADS ... of the queue and has its own head word
+// on its own 128-byte line (one hot word answers only ~90 atomics/us chip-wide; sixteen words let the
+// traversal waves refill a few lanes at a time while all streams together still advance as one
+// compact window over the queue).
+enum {
+    PT_HEADS = 16,
+    PT_HEAD_STRIDE = 32,  // words between head words
+    PT_CTR_COUNT = 0,
+    PT_CTR_SHADOW_COUNT = 1,
+    PT_CTR_HEAD_CLOSEST = PT_HEAD_STRIDE,
+    PT_CTR_HEAD_SHADOW = PT_HEAD_STRIDE * (1 + PT_HEADS),
+    PT_CTR_STRIDE = PT_HEAD_STRIDE * (1 + 2 * PT_HEADS)
+};
 
 struct PtScene {
     const float4* nodes;     // 5 x float4 (80 B) per compressed 8-wide BVH node (bvh_build.h layout)
