@@ -126,7 +126,8 @@ class SpheresWorkload:
     def roofline(self):
         """HIP-event duration of each kernel (profile_stages) -> dominant kernel vs the HBM roofline.
         Algorithmic bytes: cone level = 8 B/thread (4 B parent read + 4 B store),
-        shade = 16 B/pixel (4 B depth read + 12 B rgb store)."""
+        shade = 4 B depth read per sample + 12 B rgb store per pixel; the per-level schedule puts the
+        spp samples (up to 16) of a pixel into ONE launch per level and one shade launch."""
         cfg = self.r.default_config()
         cfg.profile_stages = 1
         self.r.set_config(cfg)
@@ -146,8 +147,9 @@ class SpheresWorkload:
             kernels = {"pyramid_tile_kernel": (fused, sum(w * h for w, h in dims) * 4.0),
                        "shade_kernel": (sh, self.width * self.height * 16.0)}
         else:
-            kernels = {f"cone_level_kernel(level {last})": (lv[last], dims[last][0] * dims[last][1] * 8.0),
-                       "shade_kernel": (sh, self.width * self.height * 16.0)}
+            nb = min(self.spp, 16)
+            kernels = {f"cone_level_kernel(level {last})": (lv[last], dims[last][0] * dims[last][1] * 8.0 * nb),
+                       "shade_kernel": (sh, self.width * self.height * (4.0 * nb + 12.0))}
         name = max(kernels, key=lambda k: kernels[k][0])
         ms, nbytes = kernels[name]
         achieved = nbytes / (ms * 1e-3) / 1e9

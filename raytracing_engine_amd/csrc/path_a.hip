@@ -93,8 +93,11 @@ __global__ __launch_bounds__(256) void cone_level_kernel(const SphereSet S, cons
         if (!owns_pixel_tile(p.part, (tx * 8u) << p.shift, (ty * 8u) << p.shift, p.width, p.height)) return;
     }
     const uint32_t gx = tx * 8u + (lane & 7u), gy = ty * 8u + (lane >> 3);
-    const float len0 = p.level > 0 ? parent[(size_t)(gy >> 1) * p.parent_w + (gx >> 1)] : 1.0f;  // :79-82
-    out[(size_t)gy * p.w + gx] = cone_pixel<N>(S.s, p.cam, p.image_size[0], p.image_size[1], gx, gy, len0, p.render_dist, p.max_steps);
+    const uint32_t b = blockIdx.y;  // sample of the batch: its own jitter, its own level images
+    Camera cam = p.cam;
+    sample_jitter(p.sample0 + b, p.n_strata, p.width, p.height, &cam.jitter[0], &cam.jitter[1]);
+    const float len0 = p.level > 0 ? parent[(size_t)b * p.parent_stride + (size_t)(gy >> 1) * p.parent_w + (gx >> 1)] : 1.0f;  // :79-82
+    out[(size_t)b * p.level_stride + (size_t)gy * p.w + gx] = cone_pixel<N>(S.s, cam, p.image_size[0], p.image_size[1], gx, gy, len0, p.render_dist, p.max_steps);
 }
 
 // ---- shaders/fragment.glsl:89-121 -------------------------------------------------------------
@@ -141,13 +144,13 @@ __device__ __forceinline__ float4 pick8(const float4 (&a)[8], uint32_t i) {
 // One invocation of fragment.glsl:main for full-resolution pixel (px, py) whose depth is total_dist.
 // Returns true for a hit pixel; rgb = 0 for a miss (:137-140).
 template <int N>
-__device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams p, uint32_t px, uint32_t py, float total_dist, float& r, float& g,
-                                            float& b) {
+__device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams p, float jx, float jy, uint32_t px, uint32_t py, float total_dist, float& r,
+                                            float& g, float& b) {
     r = g = b = 0.0f;
     if (!(total_dist < p.render_dist)) return false;  // :137-140
     // :129-133  gl_FragCoord.xy * 2 / cs.view - 1.0   (gl_FragCoord = pixel + 0.5)
-    float nx = (((float)px + 0.5f) * 2.0f) / p.view[0] - 1.0f + p.cam.jitter[0];
-    float ny = (((float)py + 0.5f) * 2.0f) / p.view[1] - 1.0f + p.cam.jitter[1];
+    float nx = (((float)px + 0.5f) * 2.0f) / p.view[0] - 1.0f + jx;
+    float ny = (((float)py + 0.5f) * 2.0f) / p.view[1] - 1.0f + jy;
     nx *= p.cam.ratio[0];
     ny *= p.cam.ratio[1];
     const v3 step = normalize(rotate_q(p.cam.rot[0], p.cam.rot[1], p.cam.rot[2], p.cam.rot[3], mk(nx, 1.0f, ny)));
@@ -203,24 +206,6 @@ __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams 
     return true;
 }
 
-// Store one shaded sample: overwrite, or add to the running sum (samples in index order:
-// ((s0 + s1) + s2) + ...), dividing by spp after the last one.
-__device__ __forceinline__ void store_sample(const ShadeParams p, float* o, float r, float g, float b) {
-    if (p.mode & 1u) {
-        r = o[0] + r;
-        g = o[1] + g;
-        b = o[2] + b;
-    }
-    if (p.mode & 2u) {
-        r = r / p.spp;
-        g = g / p.spp;
-        b = b / p.spp;
-    }
-    o[0] = r;
-    o[1] = g;
-    o[2] = b;
-}
-
 // Grid: 16 workgroups per owned framebuffer tile; every wave shades one 8x8 block of the tile.
 template <int N>
 __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const ShadeParams p, const float* __restrict__ depth,
@@ -234,17 +219,47 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
     const uint32_t px = tile_x * RT_TILE + lx, py = tile_y * RT_TILE + ly;
     const bool inside = px < p.width && py < p.height;
 
+    // the samples of the batch in index order, continuing the running sum of earlier batches:
+    // ((s0 + s1) + s2) + ... exactly what one launch per sample gives
+    const size_t idx = p.tile_major ? ((size_t)k * (RT_TILE * RT_TILE) + (size_t)ly * RT_TILE + lx) : ((size_t)py * p.width + px);
     float r = 0.0f, g = 0.0f, b = 0.0f;
-    const bool hit = inside && shade_pixel<N>(S, p, px, py, depth[(size_t)py * p.depth_w + px], r, g, b);  // :135
-
-    const unsigned long long hits = __ballot(hit);
+    bool have_sum = false;
+    if ((p.mode & 1u) && inside) {
+        r = dst[idx * 3];
+        g = dst[idx * 3 + 1];
+        b = dst[idx * 3 + 2];
+        have_sum = true;
+    }
+    uint32_t n_hits = 0;
+    for (uint32_t sb = 0; sb < p.n_batch; sb++) {
+        float jx, jy, sr, sg, sbl;
+        sample_jitter(p.sample0 + sb, p.n_strata, p.width, p.height, &jx, &jy);
+        const bool hit = inside && shade_pixel<N>(S, p, jx, jy, px, py, depth[(size_t)sb * p.depth_stride + (size_t)py * p.depth_w + px], sr, sg, sbl);  // :135
+        if (have_sum) {
+            r += sr;
+            g += sg;
+            b += sbl;
+        } else {
+            r = sr;
+            g = sg;
+            b = sbl;
+            have_sum = true;
+        }
+        n_hits += (uint32_t)__popcll(__ballot(hit));
+    }
     // hit-pixel statistics: one atomic per wave, spread over 1024 slots (a single hot word serves only
     // ~90 atomics/us chip-wide and made this kernel atomic-bound); the host sums the slots
-    if (lane == 0 && hits) atomicAdd((unsigned long long*)&counters[blockIdx.x & 1023u], (unsigned long long)__popcll(hits));
+    if (lane == 0 && n_hits) atomicAdd((unsigned long long*)&counters[blockIdx.x & 1023u], (unsigned long long)n_hits);
 
     if (inside) {
-        const size_t idx = p.tile_major ? ((size_t)k * (RT_TILE * RT_TILE) + (size_t)ly * RT_TILE + lx) : ((size_t)py * p.width + px);
-        store_sample(p, dst + idx * 3, r, g, b);
+        if (p.mode & 2u) {
+            r = r / p.spp;
+            g = g / p.spp;
+            b = b / p.spp;
+        }
+        dst[idx * 3] = r;
+        dst[idx * 3 + 1] = g;
+        dst[idx * 3 + 2] = b;
     }
 }
 
@@ -362,12 +377,13 @@ static void shade_launch_n(hipStream_t st, dim3 grid, const ShadeSet& S, const S
     hipLaunchKernelGGL(shade_kernel<N>, grid, dim3(256), 0, st, S, p, depth, dst, counters);
 }
 
-int launch_cone_level(Ctx* c, const SphereSet& S, uint32_t n_obj, const ConeLevelParams& p, const float* parent, float* out) {
+int launch_cone_level(Ctx* c, const SphereSet& S, uint32_t n_obj, const ConeLevelParams& p, const float* parent, float* out, uint32_t batch) {
     if (n_obj < 1 || n_obj > RT_MAX_OBJECTS) return c->fail(RT_ERR_INVALID, "objCount %u out of [1,8]", n_obj);
     if ((p.w & 7u) || (p.h & 7u) || p.w == 0 || p.h == 0) return c->fail(RT_ERR_INVALID, "level dims %ux%u not multiples of 8", p.w, p.h);
+    if (batch < 1 || batch > 65535u || p.n_strata < 1) return c->fail(RT_ERR_INVALID, "sample batch %u / strata %u", batch, p.n_strata);
     if (p.level > 0 && (parent == nullptr || p.parent_w * 2u < p.w)) return c->fail(RT_ERR_INVALID, "level %u: bad parent image", p.level);
     const uint32_t tiles = (p.w >> 3) * (p.h >> 3);
-    const dim3 grid((tiles + 3u) / 4u);
+    const dim3 grid((tiles + 3u) / 4u, batch);
     switch (n_obj) {
         case 1: cone_launch_n<1>(c->stream, grid, S, p, parent, out); break;
         case 2: cone_launch_n<2>(c->stream, grid, S, p, parent, out); break;
@@ -385,6 +401,7 @@ int launch_cone_level(Ctx* c, const SphereSet& S, uint32_t n_obj, const ConeLeve
 int launch_shade(Ctx* c, const ShadeSet& S, uint32_t n_obj, const ShadeParams& p, const float* depth, float* dst, uint64_t* counters) {
     if (n_obj < 1 || n_obj > RT_MAX_OBJECTS) return c->fail(RT_ERR_INVALID, "objCount %u out of [1,8]", n_obj);
     if (p.depth_w < p.width) return c->fail(RT_ERR_INVALID, "depth pitch %u < width %u", p.depth_w, p.width);
+    if (p.n_batch < 1 || p.n_strata < 1) return c->fail(RT_ERR_INVALID, "sample batch %u / strata %u", p.n_batch, p.n_strata);
     const uint32_t total = p.part.tiles_x * p.part.tiles_y;
     if (p.part.n_ranks == 0 || p.part.rank >= p.part.n_ranks) return c->fail(RT_ERR_INVALID, "bad partition");
     const uint32_t owned = total > p.part.rank ? (total - p.part.rank + p.part.n_ranks - 1u) / p.part.n_ranks : 0u;

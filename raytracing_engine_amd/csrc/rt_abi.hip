@@ -43,6 +43,8 @@ void free_frame(Ctx* c) {
     }
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     c->d_rgb = nullptr;
+    c->level_batch = 0;
+    c->last_image = 0;
     c->frame_valid = false;
 }
 
@@ -82,25 +84,46 @@ uint32_t strata_of(uint32_t spp) {
     return 0;
 }
 
-// Enqueue one full frame (all pyramid levels + shading) for sample s of spp.
-int enqueue_sample(Ctx* c, const float rot[4], const float pos[3], uint32_t s, uint32_t n_strata, uint32_t spp, float* dst,
-                   int tile_major, bool stage_events) {
+// Samples of one pixel are independent full frames, so up to kSampleBatch of them share each launch
+// (grid.y = sample for the pyramid levels, an in-thread loop in index order for shading): the coarse
+// levels are latency-bound chains of a few hundred threads and cost the same for 1 or 16 samples.
+constexpr uint32_t kSampleBatch = 16;
+
+// Every level holds `batch` images (one per sample of a batch).
+int ensure_levels(Ctx* c, uint32_t batch) {
+    if (batch <= c->level_batch) return RT_OK;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < c->level_count; i++) {
+        if (c->d_level[i]) (void)hipFree(c->d_level[i]);
+        c->d_level[i] = nullptr;
+    }
+    c->level_batch = 0;
+    c->frame_valid = false;
+    for (uint32_t i = 0; i < c->level_count; i++) {
+        const size_t bytes = (size_t)c->dims[i][0] * c->dims[i][1] * sizeof(float) * batch;
+        if (hipMalloc((void**)&c->d_level[i], bytes) != hipSuccess || hipMemset(c->d_level[i], 0, bytes) != hipSuccess)
+            return c->fail(RT_ERR_OOM, "pyramid level %u x %u samples (%zu bytes)", i, batch, bytes);
+    }
+    c->level_batch = batch;
+    return RT_OK;
+}
+
+// Enqueue samples s0 .. s0 + nb - 1 of spp: all pyramid levels, then shading (which adds the samples
+// to the running sum in index order).
+int enqueue_samples(Ctx* c, const float rot[4], const float pos[3], uint32_t s0, uint32_t nb, uint32_t n_strata, uint32_t spp, float* dst,
+                    int tile_major, bool stage_events) {
     rt::Camera cam{};
     std::memcpy(cam.rot, rot, 16);
     std::memcpy(cam.pos, pos, 12);
     cam.ratio[0] = c->ratio[0];
     cam.ratio[1] = c->ratio[1];
-    // stratified sub-pixel centre (i+0.5)/n inside the pixel -> NDC offset ((2i+1)/n - 1)/view;
-    // n = 1 gives exactly 0, i.e. the reference's pixel-centre sample.
-    const uint32_t si = s % n_strata, sj = s / n_strata;
-    cam.jitter[0] = ((float)(2u * si + 1u) / (float)n_strata - 1.0f) / (float)c->width;
-    cam.jitter[1] = ((float)(2u * sj + 1u) / (float)n_strata - 1.0f) / (float)c->height;
+    rt::sample_jitter(s0, n_strata, c->width, c->height, &cam.jitter[0], &cam.jitter[1]);  // used by the fused schedule (nb = 1)
 
     const uint32_t count = c->level_count;
     uint32_t ev = 0;
     rt::SphereSet spheres;
     fill_sphere_set(c->scene, &spheres);
-    if (c->cfg.fuse_levels) {  // one launch for the whole pyramid (path_a.hip pyramid_tile_kernel)
+    if (c->cfg.fuse_levels) {  // one launch for the whole pyramid (path_a.hip pyramid_tile_kernel), one sample at a time
         rt::PyramidParams fp{};
         fp.cam = cam;
         fp.width = c->width;
@@ -137,8 +160,12 @@ int enqueue_sample(Ctx* c, const float rot[4], const float pos[3], uint32_t s, u
             p.max_steps = c->cfg.max_steps;
             p.part = c->part;
             p.partitioned = partitioned ? 1u : 0u;
+            p.sample0 = s0;
+            p.n_strata = n_strata;
+            p.level_stride = c->dims[i][0] * c->dims[i][1];
+            p.parent_stride = i ? c->dims[i - 1][0] * c->dims[i - 1][1] : 0;
             if (stage_events) RT_HIP(c, hipEventRecord(c->ev_stage[ev++], c->stream));
-            int rc = rt::launch_cone_level(c, spheres, c->scene.objCount, p, i ? c->d_level[i - 1] : nullptr, c->d_level[i]);
+            int rc = rt::launch_cone_level(c, spheres, c->scene.objCount, p, i ? c->d_level[i - 1] : nullptr, c->d_level[i], nb);
             if (rc) return rc;
         }
     }
@@ -160,11 +187,16 @@ int enqueue_sample(Ctx* c, const float rot[4], const float pos[3], uint32_t s, u
     sp.max_steps = c->cfg.max_steps;
     sp.part = c->part;
     sp.tile_major = tile_major ? 1u : 0u;
-    sp.mode = (s > 0 ? 1u : 0u) | ((spp > 1 && s + 1 == spp) ? 2u : 0u);
+    sp.mode = (s0 > 0 ? 1u : 0u) | ((spp > 1 && s0 + nb == spp) ? 2u : 0u);
     sp.spp = (float)spp;
+    sp.sample0 = s0;
+    sp.n_batch = nb;
+    sp.n_strata = n_strata;
+    sp.depth_stride = c->dims[count - 1][0] * c->dims[count - 1][1];
     int rc = rt::launch_shade(c, set, c->scene.objCount, sp, c->d_level[count - 1], dst, c->d_counters);
     if (rc) return rc;
     if (stage_events) RT_HIP(c, hipEventRecord(c->ev_stage[ev++], c->stream));
+    c->last_image = nb - 1u;
     return RT_OK;
 }
 
@@ -180,9 +212,12 @@ int render_common(Ctx* c, const float rot[4], const float pos[3], uint32_t spp, 
     const bool stage_events = c->cfg.profile_stages != 0;
     RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 1024 * sizeof(uint64_t), c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
-    for (uint32_t s = 0; s < spp; s++) {
-        // per-stage events only bracket the last sample (ev_stage is reused per sample)
-        int rc = enqueue_sample(c, rot, pos, s, n_strata, spp, dst_dev, tile_major, stage_events && s + 1 == spp);
+    const uint32_t batch = c->cfg.fuse_levels ? 1u : std::min(spp, kSampleBatch);
+    if (int rc = ensure_levels(c, batch)) return rc;
+    for (uint32_t s = 0; s < spp; s += batch) {
+        // per-stage events only bracket the last batch (ev_stage is reused per batch)
+        const uint32_t nb = std::min(batch, spp - s);
+        int rc = enqueue_samples(c, rot, pos, s, nb, n_strata, spp, dst_dev, tile_major, stage_events && s + nb == spp);
         if (rc) return rc;
     }
     RT_HIP(c, hipEventRecord(c->ev_end, c->stream));
@@ -380,13 +415,12 @@ int rt_resize(rt_ctx* ctx, uint32_t width, uint32_t height, const float ratio[2]
     free_frame(c);
     c->width = c->height = 0;
     const uint32_t count = level_count_for(width);
-    for (uint32_t i = 0; i < count; i++) {
-        level_dims_for(width, height, count, i, &c->dims[i][0], &c->dims[i][1]);
-        const size_t bytes = (size_t)c->dims[i][0] * c->dims[i][1] * sizeof(float);
-        if (hipMalloc((void**)&c->d_level[i], bytes) != hipSuccess || hipMemset(c->d_level[i], 0, bytes) != hipSuccess) {
-            free_frame(c);
-            return c->fail(RT_ERR_OOM, "pyramid level %u (%zu bytes)", i, bytes);
-        }
+    for (uint32_t i = 0; i < count; i++) level_dims_for(width, height, count, i, &c->dims[i][0], &c->dims[i][1]);
+    c->level_count = count;
+    if (int rc = ensure_levels(c, 1)) {
+        free_frame(c);
+        c->level_count = 0;
+        return rc;
     }
     if (hipMalloc((void**)&c->d_rgb, (size_t)width * height * 3 * sizeof(float)) != hipSuccess) {
         free_frame(c);
@@ -466,7 +500,7 @@ int rt_render(rt_ctx* ctx, const float rot[4], const float pos[3], float* rgb_ou
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (depth_out) {
         const uint32_t l = c->level_count - 1;
-        RT_HIP(c, hipMemcpy(depth_out, c->d_level[l], (size_t)c->dims[l][0] * c->dims[l][1] * sizeof(float), hipMemcpyDeviceToHost));
+        RT_HIP(c, hipMemcpy(depth_out, c->d_level[l] + (size_t)c->last_image * c->dims[l][0] * c->dims[l][1], (size_t)c->dims[l][0] * c->dims[l][1] * sizeof(float), hipMemcpyDeviceToHost));
     }
     return RT_OK;
 }
@@ -511,7 +545,8 @@ int rt_read_level(rt_ctx* ctx, uint32_t level, float* out, uint32_t* w, uint32_t
     if (h) *h = c->dims[level][1];
     if (out) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
-        RT_HIP(c, hipMemcpy(out, c->d_level[level], (size_t)c->dims[level][0] * c->dims[level][1] * sizeof(float), hipMemcpyDeviceToHost));
+        RT_HIP(c, hipMemcpy(out, c->d_level[level] + (size_t)c->last_image * c->dims[level][0] * c->dims[level][1], (size_t)c->dims[level][0] * c->dims[level][1] * sizeof(float),
+                            hipMemcpyDeviceToHost));
     }
     return RT_OK;
 }

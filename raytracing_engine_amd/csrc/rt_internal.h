@@ -60,6 +60,10 @@ struct ConeLevelParams {
     uint32_t max_steps;
     Partition part;
     uint32_t partitioned;  // 1: skip level tiles this rank does not own / that are off-screen
+    // sample batch: blockIdx.y = b traces sample sample0 + b of an n_strata x n_strata stratified pixel
+    // into image b of the level (images level_stride floats apart; parents parent_stride apart)
+    uint32_t sample0, n_strata;
+    uint32_t level_stride, parent_stride;
 };
 
 struct ShadeParams {
@@ -73,7 +77,20 @@ struct ShadeParams {
     uint32_t tile_major;  // 0: dst is a full frame, 1: dst holds owned tiles packed tile-major
     uint32_t mode;        // bit0: accumulate onto dst, bit1: divide by spp after adding
     float spp;
+    // sample batch: the kernel shades samples sample0 .. sample0 + n_batch - 1 of the pixel in index
+    // order (depth image b is depth_stride floats after image 0) and adds them in that order
+    uint32_t sample0, n_batch, n_strata;
+    uint32_t depth_stride;
 };
+
+// Sub-pixel offset of sample s of an n x n stratified pixel in NDC: the stratum centre (i + 0.5)/n inside
+// the pixel is ((2i + 1)/n - 1)/view; n = 1 gives exactly 0 = the reference's pixel-centre sample.  The
+// same IEEE expression on host and device (correctly rounded divisions on both).
+__host__ __device__ inline void sample_jitter(uint32_t s, uint32_t n, uint32_t width, uint32_t height, float* jx, float* jy) {
+    const uint32_t si = s % n, sj = s / n;
+    *jx = ((float)(2u * si + 1u) / (float)n - 1.0f) / (float)width;
+    *jy = ((float)(2u * sj + 1u) / (float)n - 1.0f) / (float)height;
+}
 
 // One-launch pyramid: every level for a 32x32 pixel block per workgroup (path_a.hip)
 struct PyramidParams {
@@ -185,7 +202,9 @@ struct Ctx {
     float ratio[2] = {1.0f, 1.0f};
     uint32_t level_count = 0;
     uint32_t dims[RT_MAX_LEVELS][2] = {};
-    float* d_level[RT_MAX_LEVELS] = {};
+    float* d_level[RT_MAX_LEVELS] = {};  // level i: level_batch images of dims[i], one per sample of a batch
+    uint32_t level_batch = 0;            // images allocated per level
+    uint32_t last_image = 0;             // image of the batch that holds the last sample rendered
     float* d_rgb = nullptr;         // full frame, f32 x 3
     uint64_t* d_counters = nullptr;  // 1024 slots of hit-pixel counts, summed on the host
     Partition part{0, 1, 0, 0};
@@ -218,7 +237,7 @@ struct Ctx {
 
 // path_a.hip
 int launch_cone_level(Ctx* c, const SphereSet& spheres, uint32_t n_obj, const ConeLevelParams& p, const float* parent,
-                      float* out);
+                      float* out, uint32_t batch);
 int launch_shade(Ctx* c, const ShadeSet& set, uint32_t n_obj, const ShadeParams& p, const float* depth, float* dst,
                  uint64_t* counters);
 int launch_pyramid_fused(Ctx* c, const SphereSet& spheres, uint32_t n_obj, const PyramidParams& fp);
