@@ -21,6 +21,11 @@
  *   swapchain *_UNORM colour attachment  src/main.rs:471-486       rt_read_rgba8
  *   (none: the reference cannot read a pyramid level back)         rt_read_level  [test hook]
  *   FPS println  src/main.rs:719,730                               rt_get_stats
+ *   swapchain images + one fence per image: wait the image's fence,
+ *     record, submit after the previous frame, present
+ *     src/main.rs:664-667, 882-927                                 rt_frames_configure /
+ *                                                                  rt_frame_submit(_pt) /
+ *                                                                  rt_frame_wait / rt_frame_poll
  *
  * Conventions: every function returns RT_OK (0) or a negative rt_status and never throws or
  * aborts across the boundary; the caller owns every host/device pointer it passes; the context
@@ -170,6 +175,25 @@ int rt_read_rgba8(rt_ctx* ctx, uint8_t* rgba_out);
 
 int rt_get_stats(const rt_ctx* ctx, rt_stats* stats);
 
+/* Frames in flight - the reference's swapchain loop (src/main.rs:664-667, 882-927: one fence per
+ * swapchain image; a frame waits for its image's fence, is recorded, submitted behind the previous
+ * frame and presented) with "present" = the pixels arriving in host memory.  A slot is one swapchain
+ * image: a device frame, a pinned host frame and two events.  rt_frame_submit waits until the slot's
+ * previous frame has reached the host (the image fence, :882-884), enqueues the render on the
+ * context's stream and the read-back on a copy stream behind it, and returns without waiting; the
+ * read-back of frame k overlaps the render of frame k+1.  rt_frame_wait blocks until the slot's
+ * pixels are in host memory and returns a pointer that stays valid until the slot is submitted
+ * again.  format RT_FRAME_F32 = width*height*3 f32 (linear RGB), RT_FRAME_RGBA8 = width*height*4
+ * bytes as rt_read_rgba8 defines them.  rt_resize releases the slots: configure again afterwards.
+ * Single-rank contexts only (a partitioned context gathers tiles instead). */
+#define RT_FRAME_F32 0u
+#define RT_FRAME_RGBA8 1u
+#define RT_MAX_FRAME_SLOTS 8u
+int rt_frames_configure(rt_ctx* ctx, uint32_t n_slots, uint32_t format);
+int rt_frame_submit(rt_ctx* ctx, uint32_t slot, const float rot[4], const float pos[3], uint32_t spp);
+int rt_frame_wait(rt_ctx* ctx, uint32_t slot, const void** pixels, size_t* bytes);
+int rt_frame_poll(rt_ctx* ctx, uint32_t slot, int* ready);
+
 /* ------------------------------------------------------------------------------------------------
  * Path B — build-defined extension (BASELINE.json configs[2..4]): triangle meshes, a BVH and a
  * wavefront path tracer.  NO REFERENCE COUNTERPART: the reference has only sphere SDFs, one
@@ -213,6 +237,8 @@ int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const floa
 int rt_render_pt(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, float* rgb_out);
 /* Asynchronous device-side variant, same output layouts as rt_render_device. */
 int rt_render_pt_device(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, void* rgb_dev, int tile_major);
+/* Path B frame into a frames-in-flight slot (see rt_frame_submit). */
+int rt_frame_submit_pt(rt_ctx* ctx, uint32_t slot, const float rot[4], const float pos[3], const rt_pt_params* params);
 int rt_get_pt_stats(rt_ctx* ctx, rt_pt_stats* stats);
 /* Test hook: trace n caller-supplied rays (host arrays, n*3 each).  any_hit = 0: closest hit,
  * t_out[i] = distance (inf on miss), tri_out[i] = original triangle index or -1;

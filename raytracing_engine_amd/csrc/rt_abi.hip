@@ -365,6 +365,7 @@ void rt_destroy(rt_ctx* ctx) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    rt::frames_free(c);
     rt::comm_free(c);
     free_frame(c);
     rt::pt_free(c);
@@ -412,6 +413,7 @@ int rt_resize(rt_ctx* ctx, uint32_t width, uint32_t height, const float ratio[2]
     if (width == 0 || height == 0 || width > 16384 || height > 16384) return c->fail(RT_ERR_INVALID, "view %ux%u out of range", width, height);
     if (int rc = bind(c)) return rc;
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    rt::frames_free(c);  // slots are sized for the old view
     free_frame(c);
     c->width = c->height = 0;
     const uint32_t count = level_count_for(width);

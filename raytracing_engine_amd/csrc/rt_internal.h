@@ -215,6 +215,7 @@ struct Ctx {
     bool frame_valid = false;
     PtData pt;
     int n_cus = 256;
+    void* frames = nullptr;  // frames-in-flight slots (rt_abi_frames.hip)
     void* comm = nullptr;  // ncclComm_t once rt_comm_init ran (rt_abi_comm.hip)
     uint32_t comm_rank = 0, comm_ranks = 1;
 
@@ -234,6 +235,8 @@ struct Ctx {
         hipError_t e_ = (call);                                                                    \
         if (e_ != hipSuccess) return (ctx)->fail(RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+
+void frames_free(Ctx* c);  // rt_abi_frames.hip: waits for frames in flight, releases every slot
 
 // path_a.hip
 int launch_cone_level(Ctx* c, const SphereSet& spheres, uint32_t n_obj, const ConeLevelParams& p, const float* parent,

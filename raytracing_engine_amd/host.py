@@ -248,6 +248,40 @@ class Renderer:
         self._check(self._lib.rt_read_rgba8(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
+    # ---- frames in flight (src/main.rs:664-667, 882-927: one fence per swapchain image) -----------
+    FRAME_F32, FRAME_RGBA8 = 0, 1
+
+    def frames_configure(self, n_slots=3, fmt=0):
+        """n_slots swapchain-image-like slots; fmt FRAME_F32 (H,W,3 f32) or FRAME_RGBA8 (H,W,4 u8)."""
+        self._check(self._lib.rt_frames_configure(self._ctx, int(n_slots), int(fmt)))
+        self._frame_fmt = int(fmt)
+
+    def frame_submit(self, slot, rot=(0, 0, 0, 1), pos=(0, 0, 0), spp=1, pt_params=None):
+        """Enqueue a frame into `slot` (waits for the slot's previous frame first) and return at once;
+        path A by default, path B when pt_params is given."""
+        rot = np.ascontiguousarray(rot, np.float32)
+        pos = np.ascontiguousarray(pos, np.float32)
+        if pt_params is None:
+            self._check(self._lib.rt_frame_submit(self._ctx, int(slot), _fptr(rot), _fptr(pos), int(spp)))
+        else:
+            self._check(self._lib.rt_frame_submit_pt(self._ctx, int(slot), _fptr(rot), _fptr(pos), C.byref(pt_params)))
+
+    def frame_wait(self, slot, copy=True):
+        """Block until the slot's pixels are in host memory -> array (a view of the pinned frame when
+        copy=False: valid until the slot is submitted again)."""
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.rt_frame_wait(self._ctx, int(slot), C.byref(ptr), C.byref(nbytes)))
+        if self._frame_fmt == self.FRAME_RGBA8:
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(self.height, self.width, 4))
+        else:
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(self.height, self.width, 3))
+        return a.copy() if copy else a
+
+    def frame_ready(self, slot):
+        r = C.c_int()
+        self._check(self._lib.rt_frame_poll(self._ctx, int(slot), C.byref(r)))
+        return bool(r.value)
+
     def stats(self):
         s = Stats()
         self._check(self._lib.rt_get_stats(self._ctx, C.byref(s)))

@@ -1,0 +1,91 @@
+"""Frames in flight (reference src/main.rs:664-667, 882-927) through the C ABI:
+the pipelined slots must deliver exactly the frames the synchronous entry points deliver."""
+import numpy as np
+import pytest
+
+import raytracing_engine_amd as R
+
+pytestmark = pytest.mark.gpu
+
+W, H = 320, 200
+
+
+@pytest.fixture(scope="module")
+def r():
+    r = R.Renderer(0)
+    r.set_scene(R.cornell_scene())
+    r.resize(W, H)
+    return r
+
+
+def cameras(n):
+    return [(R.camera_quat(0.05 * k, -0.02 * k), (0.1 * k, 0.05 * k, 0.0)) for k in range(n)]
+
+
+def test_slots_deliver_the_synchronous_frames(r):
+    cams = cameras(7)
+    want = [r.render(rot, pos, spp=1).copy() for rot, pos in cams]
+    r.frames_configure(3, r.FRAME_F32)
+    got = [None] * len(cams)
+    for k, (rot, pos) in enumerate(cams):  # the swapchain loop: submit frame k, collect frame k-2
+        r.frame_submit(k % 3, rot, pos, spp=1)
+        if k >= 2:
+            got[k - 2] = r.frame_wait((k - 2) % 3)
+    for k in (len(cams) - 2, len(cams) - 1):
+        got[k] = r.frame_wait(k % 3)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+
+
+def test_resubmitting_a_busy_slot_waits_for_its_fence(r):
+    cams = cameras(4)
+    r.frames_configure(1, r.FRAME_F32)
+    for rot, pos in cams:  # never waited: every submit has to wait for the slot itself
+        r.frame_submit(0, rot, pos, spp=4)
+    assert np.array_equal(r.frame_wait(0), r.render(*cams[-1], spp=4))
+    assert r.frame_ready(0)
+
+
+def test_rgba8_slots_match_read_rgba8(r):
+    rot, pos = cameras(3)[2]
+    r.render(rot, pos, spp=1)
+    want = r.read_rgba8()
+    r.frames_configure(2, r.FRAME_RGBA8)
+    r.frame_submit(1, rot, pos, spp=1)
+    got = r.frame_wait(1)
+    assert got.dtype == np.uint8 and got.shape == (H, W, 4)
+    assert np.array_equal(got, want)
+
+
+def test_path_b_frames(r):
+    mesh = R.scenes.cornell_tri_scene()
+    r.set_mesh(*mesh)
+    prm = r.pt_params(spp=2, bounces=1, seed=3)
+    want = [r.render_pt(pos=(0.0, 1.0 + 0.1 * k, 0.0), params=prm) for k in range(3)]
+    r.frames_configure(2, r.FRAME_F32)
+    got = []
+    for k in range(3):
+        r.frame_submit(k % 2, pos=(0.0, 1.0 + 0.1 * k, 0.0), pt_params=prm)
+        if k >= 1:
+            got.append(r.frame_wait((k - 1) % 2))
+    got.append(r.frame_wait(0))
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+
+
+def test_error_behaviour(r):
+    r.frames_configure(2, r.FRAME_F32)
+    with pytest.raises(R.RtError):
+        r.frame_submit(2)  # no such slot
+    with pytest.raises(R.RtError):
+        r.frame_wait(1)  # nothing submitted to it
+    with pytest.raises(R.RtError):
+        r.frames_configure(0)
+    with pytest.raises(R.RtError):
+        r.frames_configure(2, 7)
+    r.resize(W, H)  # releases the slots
+    with pytest.raises(R.RtError):
+        r.frame_submit(0)
+    r.frames_configure(2, r.FRAME_F32)
+    r.frame_submit(0)
+    assert r.frame_wait(0).shape == (H, W, 3)
