@@ -8,6 +8,8 @@
 //
 //   rt_host [--size WxH] [--yaw R] [--pitch R] [--pos x,y,z] [--move right,forward,up] [--spp N]
 //           [--scene default|soup:N] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm]
+//           [--march 1|2|3] [--repeat x,y,z] [--inflight K]
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -103,6 +105,8 @@ int main(int argc, char** argv) {
     uint32_t w = 1024, h = 768, spp = 1, bounces = 1, seed = 1, frames = 1;
     float yaw = 0.0f, pitch = 0.0f, pos[3] = {0, 0, 0}, move[3] = {0, 0, 0};
     std::string scene = "default", out = "frame.ppm";
+    uint32_t march = 0, inflight = 0;
+    float repeat[3] = {0, 0, 0};
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -117,9 +121,13 @@ int main(int argc, char** argv) {
         else if (a == "--frames") frames = (uint32_t)std::atoi(next());
         else if (a == "--scene") scene = next();
         else if (a == "--out") out = next();
+        else if (a == "--march") march = (uint32_t)std::atoi(next());
+        else if (a == "--repeat") std::sscanf(next(), "%f,%f,%f", &repeat[0], &repeat[1], &repeat[2]);
+        else if (a == "--inflight") inflight = (uint32_t)std::atoi(next());
         else {
             std::fprintf(stderr, "usage: rt_host [--size WxH] [--yaw R] [--pitch R] [--pos x,y,z] [--move r,f,u] [--spp N] "
-                                 "[--scene default|soup:N] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm]\n");
+                                 "[--scene default|soup:N] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm] "
+                                 "[--march 1|2|3] [--repeat x,y,z] [--inflight K]\n");
             return 2;
         }
     }
@@ -161,6 +169,37 @@ int main(int argc, char** argv) {
         rt_mutable_data s;
         rt_default_scene(&s);  // src/main.rs:524-591
         if ((rc = rt_set_scene(ctx, &s, sizeof s))) return fail(ctx, "rt_set_scene", rc);
+        if (march || repeat[0] > 0 || repeat[1] > 0 || repeat[2] > 0) {  // the march loops / repeat() the author sketched
+            rt_config cfg;
+            rt_default_config(&cfg);
+            cfg.march_algorithm = march;
+            for (int a = 0; a < 3; a++) cfg.repeat[a] = repeat[a];
+            if ((rc = rt_set_config(ctx, &cfg))) return fail(ctx, "rt_set_config", rc);
+        }
+    }
+    if (inflight && !tri) {
+        // the reference's frame loop with its fences (src/main.rs:664-667, 882-927): K swapchain-image slots,
+        // frame f goes to slot f % K and is collected K-1 submissions later; host-visible frames per second
+        if ((rc = rt_frames_configure(ctx, inflight, RT_FRAME_RGBA8))) return fail(ctx, "rt_frames_configure", rc);
+        const void* px = nullptr;
+        size_t nbytes = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t f = 0; f < frames; f++) {
+            if ((rc = rt_frame_submit(ctx, f % inflight, rot, pos, spp))) return fail(ctx, "rt_frame_submit", rc);
+            if (f + 1 >= inflight && (rc = rt_frame_wait(ctx, (f + 1 - inflight) % inflight, &px, &nbytes))) return fail(ctx, "rt_frame_wait", rc);
+        }
+        for (uint32_t f = frames > inflight - 1 ? frames - (inflight - 1) : 0; f < frames; f++)
+            if ((rc = rt_frame_wait(ctx, f % inflight, &px, &nbytes))) return fail(ctx, "rt_frame_wait", rc);
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("%u frame(s) %ux%u through %u slots, pixels on the host every frame: %.1f fps\n", frames, w, h, inflight, frames / sec);
+        const bool ok = px && write_ppm(out.c_str(), static_cast<const uint8_t*>(px), w, h);
+        rt_destroy(ctx);
+        if (!ok) {
+            std::fprintf(stderr, "rt_host: cannot write %s\n", out.c_str());
+            return 1;
+        }
+        std::printf("wrote %s\n", out.c_str());
+        return 0;
     }
     double ms_sum = 0.0;
     uint64_t rays = 0;

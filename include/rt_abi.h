@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -85,6 +85,11 @@ typedef struct rt_config {
     uint32_t fuse_levels;    /* 0 (default): one launch per level, the reference's schedule (src/main.rs:300-316);
                                 1: the whole depth pyramid in one launch (parent levels kept in LDS; measured slower).
                                 Same results; in fused mode level texels without a descendant inside the frame are left 0 */
+    /* SDF feature growth the author sketched; 0 / {0,0,0} = the reference as shipped.  Both need fuse_levels = 0. */
+    uint32_t march_algorithm; /* cone-march loop body: 0 or 3 = compute.glsl:46-65 ("algorithm 3");
+                                 1, 2 = shaders/tracing_algorithms.txt:2-13 / :16-37 in the same loop */
+    float repeat[3];          /* > 0: domain repetition period on that axis, repeat() of utilities.glsl:31-34,
+                                 applied to the position of every SDF evaluation and of the surface normal */
 } rt_config;
 
 typedef struct rt_stats {

@@ -45,7 +45,7 @@ class Scene(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("render_dist", C.c_float), ("cam_fall_off", C.c_float), ("light_fall_off", C.c_float),
-                ("ray_radius", C.c_float), ("max_steps", C.c_uint32)]
+                ("ray_radius", C.c_float), ("max_steps", C.c_uint32), ("march_algorithm", C.c_uint32), ("repeat", C.c_float * 3)]
 
 
 class Counters(C.Structure):

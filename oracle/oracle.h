@@ -56,6 +56,10 @@ typedef struct {
     float light_fall_off; /* LIGHT_FALL_OFF = 0.01, fragment.glsl:36 */
     float ray_radius;     /* RAY_RADIUS = 0.01, fragment.glsl:37 */
     uint32_t max_steps;   /* safety cap on either march loop (build-side; 0 = unlimited) */
+    /* SDF feature growth the author sketched; 0 / {0,0,0} = the reference as shipped */
+    uint32_t march_algorithm; /* cone march loop body: 0 or 3 = compute.glsl:46-65 ("algorithm 3"),
+                                 1, 2 = shaders/tracing_algorithms.txt:2-13 / :16-37 */
+    float repeat[3];          /* > 0: domain repetition period on that axis, utilities.glsl:31-34 */
 } ora_config;
 
 typedef struct {

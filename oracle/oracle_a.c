@@ -43,9 +43,21 @@ static inline v3 rotate_q(const float q[4], v3 v) {
     return v3_make(fmaf(2.0f, c2.x, v.x), fmaf(2.0f, c2.y, v.y), fmaf(2.0f, c2.z, v.z));
 }
 
-/* shaders/utilities.glsl:36-38   distance(p, s.pos) - s.size */
-static inline float sphere_sdf(v3 p, const ora_object* s) {
-    return v3_length(v3_sub(p, v3_load(s->pos))) - s->size;
+/* shaders/utilities.glsl:31-34   repeat(p, r) = mod(p + 0.5*r, r) - 0.5*r with GLSL's
+ * mod(x, y) = x - y*floor(x/y); applied per axis where the period is > 0 (the reference defines the
+ * function and never calls it: which positions it applies to is build-defined) */
+static inline float repeat1(float p, float r) {
+    if (!(r > 0.0f)) return p;
+    const float h = 0.5f * r, a = p + h;
+    return (a - r * floorf(a / r)) - h;
+}
+static inline v3 domain(v3 p, const ora_config* cfg) {
+    return v3_make(repeat1(p.x, cfg->repeat[0]), repeat1(p.y, cfg->repeat[1]), repeat1(p.z, cfg->repeat[2]));
+}
+
+/* shaders/utilities.glsl:36-38   distance(p, s.pos) - s.size   (p in the repeated domain) */
+static inline float sphere_sdf(v3 p, const ora_object* s, const ora_config* cfg) {
+    return v3_length(v3_sub(domain(p, cfg), v3_load(s->pos))) - s->size;
 }
 
 /* ---- public helpers ---------------------------------------------------------------------- */
@@ -55,6 +67,8 @@ void ora_default_config(ora_config* cfg) {
     cfg->light_fall_off = 0.01f; /* shaders/fragment.glsl:36 */
     cfg->ray_radius = 0.01f;     /* shaders/fragment.glsl:37 */
     cfg->max_steps = 1u << 20;
+    cfg->march_algorithm = 0;
+    cfg->repeat[0] = cfg->repeat[1] = cfg->repeat[2] = 0.0f;
 }
 
 /* src/main.rs:524-591 */
@@ -116,11 +130,11 @@ void ora_rotate(const float q[4], const float v[3], float out[3]) {
 }
 
 /* ---- shaders/compute.glsl:34-68 traceCone --------------------------------------------- */
-static float trace_cone(const ora_scene* sc, const ora_config* cfg, v3 origin, v3 step, float threshold,
-                        uint64_t* n_steps, uint64_t* n_sdf) {
+static float trace_cone3(const ora_scene* sc, const ora_config* cfg, v3 origin, v3 step, float threshold,
+                         uint64_t* n_steps, uint64_t* n_sdf) {
     float distances[ORA_MAX_OBJECTS];
     const uint32_t n = sc->objCount;
-    for (uint32_t i = 0; i < n; i++) distances[i] = sphere_sdf(origin, &sc->objs[i]); /* :37-39 */
+    for (uint32_t i = 0; i < n; i++) distances[i] = sphere_sdf(origin, &sc->objs[i], cfg); /* :37-39 */
     *n_sdf += n;
 
     float len = 0.0f, last = 0.0f;
@@ -133,7 +147,7 @@ static float trace_cone(const ora_scene* sc, const ora_config* cfg, v3 origin, v
         float radius = (len + 1.0f) * threshold;      /* :50 */
         for (uint32_t i = 0; i < n; i++) {            /* :51-57 */
             distances[i] -= last;
-            if (distances[i] <= radius) { distances[i] = sphere_sdf(position, &sc->objs[i]); (*n_sdf)++; }
+            if (distances[i] <= radius) { distances[i] = sphere_sdf(position, &sc->objs[i], cfg); (*n_sdf)++; }
             dist = fminf(dist, distances[i]);
         }
         last = fmaxf(dist, 0.0f); /* :59 */
@@ -146,12 +160,78 @@ static float trace_cone(const ora_scene* sc, const ora_config* cfg, v3 origin, v
     return len;
 }
 
+/* shaders/tracing_algorithms.txt:2-13 ("algorithm 1: checks real distance for each object every
+ * update") placed where compute.glsl:46-65 has algorithm 3; the radius is taken AFTER the step, as
+ * that listing does. */
+static float trace_cone1(const ora_scene* sc, const ora_config* cfg, v3 origin, v3 step, float threshold,
+                         uint64_t* n_steps, uint64_t* n_sdf) {
+    float len = 0.0f;
+    uint32_t it = 0;
+    while (len < cfg->render_dist) {
+        if (cfg->max_steps && it++ >= cfg->max_steps) break;
+        (*n_steps)++;
+        v3 position = v3_fma(step, len, origin);
+        float dist = sphere_sdf(position, &sc->objs[0], cfg);                                                    /* :2 */
+        for (uint32_t i = 1; i < sc->objCount; i++) dist = fminf(dist, sphere_sdf(position, &sc->objs[i], cfg)); /* :3-5 */
+        *n_sdf += sc->objCount;
+        len += dist;                                /* :7 */
+        float radius = (len + 1.0f) * threshold;    /* :8 */
+        if (dist <= radius) { len -= radius; break; } /* :9-12 */
+    }
+    return len;
+}
+
+/* shaders/tracing_algorithms.txt:16-37 ("algorithm 2: only checks real distance when necessary"):
+ * one SDF evaluation per step, of the object whose cached bound is smallest.  `distances` starts as
+ * compute.glsl:37-39 fills it; `position` is the loop-top position of compute.glsl:45, i.e. the
+ * refreshed distance belongs to the point BEFORE this step's advance - the listing read literally
+ * (the author notes its edges do not "look clean", compute.glsl:47-48). */
+static float trace_cone2(const ora_scene* sc, const ora_config* cfg, v3 origin, v3 step, float threshold,
+                         uint64_t* n_steps, uint64_t* n_sdf) {
+    float distances[ORA_MAX_OBJECTS];
+    const uint32_t n = sc->objCount;
+    for (uint32_t i = 0; i < n; i++) distances[i] = sphere_sdf(origin, &sc->objs[i], cfg);
+    *n_sdf += n;
+    uint32_t closest = 0; /* :19 */
+    float nearest = 0.0f; /* :20 */
+    float len = 0.0f;
+    uint32_t it = 0;
+    while (len < cfg->render_dist) {
+        if (cfg->max_steps && it++ >= cfg->max_steps) break;
+        (*n_steps)++;
+        v3 position = v3_fma(step, len, origin);
+        for (uint32_t i = 0; i < n; i++) { /* :22-27 */
+            distances[i] -= nearest;
+            if (distances[i] < distances[closest]) closest = i;
+        }
+        nearest = distances[closest];                                        /* :29 */
+        len += nearest;                                                      /* :30 */
+        distances[closest] = sphere_sdf(position, &sc->objs[closest], cfg);  /* :31 */
+        (*n_sdf)++;
+        float radius = (len + 1.0f) * threshold; /* :33 */
+        if (distances[closest] <= radius) {      /* :34-37 */
+            len += distances[closest] - radius;
+            break;
+        }
+    }
+    return len;
+}
+
+static float trace_cone(const ora_scene* sc, const ora_config* cfg, v3 origin, v3 step, float threshold,
+                        uint64_t* n_steps, uint64_t* n_sdf) {
+    switch (cfg->march_algorithm) {
+        case 1: return trace_cone1(sc, cfg, origin, step, threshold, n_steps, n_sdf);
+        case 2: return trace_cone2(sc, cfg, origin, step, threshold, n_steps, n_sdf);
+        default: return trace_cone3(sc, cfg, origin, step, threshold, n_steps, n_sdf);
+    }
+}
+
 /* ---- shaders/fragment.glsl:89-121 shadowRay ------------------------------------------- */
 static float shadow_ray(const ora_scene* sc, const ora_config* cfg, v3 origin, v3 step, float end,
                         uint64_t* n_steps, uint64_t* n_sdf) {
     float distances[ORA_MAX_OBJECTS];
     const uint32_t n = sc->objCount;
-    for (uint32_t i = 0; i < n; i++) distances[i] = sphere_sdf(origin, &sc->objs[i]); /* :92-94 */
+    for (uint32_t i = 0; i < n; i++) distances[i] = sphere_sdf(origin, &sc->objs[i], cfg); /* :92-94 */
     *n_sdf += n;
 
     float last = 0.0f, nearest = 1.0f; /* :96-97 */
@@ -163,7 +243,7 @@ static float shadow_ray(const ora_scene* sc, const ora_config* cfg, v3 origin, v
         float dist = end;                        /* :104 */
         for (uint32_t i = 0; i < n; i++) {       /* :105-111 */
             distances[i] -= last;
-            if (distances[i] <= nearest) { distances[i] = sphere_sdf(position, &sc->objs[i]); (*n_sdf)++; }
+            if (distances[i] <= nearest) { distances[i] = sphere_sdf(position, &sc->objs[i], cfg); (*n_sdf)++; }
             dist = fminf(dist, distances[i]);
         }
         if (dist <= cfg->ray_radius) return 0.0f; /* :113-115 */
@@ -183,22 +263,10 @@ float ora_shadow_ray(const ora_scene* scene, const ora_config* cfg, const float 
     return shadow_ray(scene, cfg, v3_load(origin), v3_load(dir), end, &a, &b);
 }
 
-/* shaders/tracing_algorithms.txt:2-13 ("algorithm 1") — every SDF re-evaluated every step;
- * the radius is taken AFTER the step, as that listing does.  Independent cross-check only. */
+/* shaders/tracing_algorithms.txt:2-13 ("algorithm 1") as an independent cross-check of algorithm 3. */
 float ora_trace_bruteforce(const ora_scene* sc, const ora_config* cfg, const float origin[3], const float dir[3], float threshold) {
-    v3 o = v3_load(origin), d = v3_load(dir);
-    float total = 0.0f;
-    uint32_t it = 0;
-    while (total < cfg->render_dist) {
-        if (cfg->max_steps && it++ >= cfg->max_steps) break;
-        v3 position = v3_fma(d, total, o);
-        float dist = sphere_sdf(position, &sc->objs[0]);                                                    /* :2 */
-        for (uint32_t i = 1; i < sc->objCount; i++) dist = fminf(dist, sphere_sdf(position, &sc->objs[i])); /* :3-5 */
-        total += dist;                                                                                      /* :7 */
-        float radius = (total + 1.0f) * threshold;                                                          /* :8 */
-        if (dist <= radius) { total -= radius; break; }                                                     /* :9-12 */
-    }
-    return total;
+    uint64_t a = 0, b = 0;
+    return trace_cone1(sc, cfg, v3_load(origin), v3_load(dir), threshold, &a, &b);
 }
 
 /* ---- shaders/compute.glsl:70-87 main, one invocation ---------------------------------- */
@@ -238,9 +306,9 @@ static inline void shade_pixel(const ora_scene* sc, const ora_config* cfg, uint3
 
     /* :144-156 nearest sphere, strict '<', material index = object index */
     uint32_t best = 0;
-    float dist = sphere_sdf(position, &sc->objs[0]);
+    float dist = sphere_sdf(position, &sc->objs[0], cfg);
     for (uint32_t i = 1; i < sc->objCount; i++) {
-        float nd = sphere_sdf(position, &sc->objs[i]);
+        float nd = sphere_sdf(position, &sc->objs[i], cfg);
         if (nd < dist) { best = i; dist = nd; }
     }
     const ora_object* object = &sc->objs[best];
@@ -248,7 +316,7 @@ static inline void shade_pixel(const ora_scene* sc, const ora_config* cfg, uint3
 
     float cam_dist = v3_length(v3_sub(position, pos));                              /* :162 */
     float cam_fall = fmaxf(cfg->cam_fall_off * fmaf(cam_dist, cam_dist, 1.0f), 1.0f); /* :163 */
-    v3 normal = v3_normalize(v3_sub(position, v3_load(object->pos)));               /* :166, :39-41 */
+    v3 normal = v3_normalize(v3_sub(domain(position, cfg), v3_load(object->pos)));  /* :166, :39-41 */
     v3 cam_dir = v3_neg(step);
     float normal_fall = fmaxf(v3_dot(normal, cam_dir), 0.0f);                       /* :167 */
 

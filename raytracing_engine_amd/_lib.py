@@ -42,7 +42,8 @@ class MutableData(C.Structure):  # shaders/compute.glsl:17-24, 656 B
 
 class Config(C.Structure):
     _fields_ = [("render_dist", C.c_float), ("cam_fall_off", C.c_float), ("light_fall_off", C.c_float),
-                ("ray_radius", C.c_float), ("max_steps", C.c_uint32), ("profile_stages", C.c_uint32), ("fuse_levels", C.c_uint32)]
+                ("ray_radius", C.c_float), ("max_steps", C.c_uint32), ("profile_stages", C.c_uint32), ("fuse_levels", C.c_uint32),
+                ("march_algorithm", C.c_uint32), ("repeat", C.c_float * 3)]
 
 
 class Stats(C.Structure):

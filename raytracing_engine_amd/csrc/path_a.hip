@@ -19,7 +19,25 @@ namespace rt {
 using namespace rtk;
 
 // shaders/utilities.glsl:36-38   distance(p, s.pos) - s.size
-__device__ __forceinline__ float sphere_sdf(v3 p, float4 s) { return length(p - mk(s.x, s.y, s.z)) - s.w; }
+// shaders/utilities.glsl:31-34  repeat(p, r) = mod(p + 0.5*r, r) - 0.5*r, mod(x, y) = x - y*floor(x/y),
+// per axis where the period is > 0.  The reference defines it and never calls it: it is applied to the
+// position of every SDF evaluation and of the surface normal (build-defined).  REP = false
+// (the reference as shipped) compiles to nothing.
+struct Rep {
+    float x, y, z;
+};
+__device__ __forceinline__ float repeat1(float p, float r) {
+    if (!(r > 0.0f)) return p;
+    const float h = 0.5f * r, a = p + h;
+    return (a - r * __builtin_floorf(a / r)) - h;
+}
+template <bool REP>
+__device__ __forceinline__ v3 domain(v3 p, Rep r) {
+    if (!REP) return p;
+    return mk(repeat1(p.x, r.x), repeat1(p.y, r.y), repeat1(p.z, r.z));
+}
+template <bool REP>
+__device__ __forceinline__ float sphere_sdf(v3 p, float4 s, Rep r) { return length(domain<REP>(p, r) - mk(s.x, s.y, s.z)) - s.w; }
 
 // Does this rank own the RT_TILE^2 tile containing full-res pixel (x0, y0)?  Off-screen -> false.
 __device__ __forceinline__ bool owns_pixel_tile(const Partition& part, uint32_t x0, uint32_t y0, uint32_t width,
@@ -30,15 +48,67 @@ __device__ __forceinline__ bool owns_pixel_tile(const Partition& part, uint32_t 
 }
 
 // ---- shaders/compute.glsl:34-68 ---------------------------------------------------------------
-template <int N>
+// ALG 3 = the loop body compute.glsl ships (:46-65); ALG 1, 2 = shaders/tracing_algorithms.txt:2-13,
+// :16-37 placed in the same loop (oracle_a.c trace_cone1/2 are the definitions).
+template <int N, int ALG, bool REP>
 __device__ __forceinline__ float trace_cone(const float4 (&sph)[RT_MAX_OBJECTS], v3 origin, v3 step, float threshold, float render_dist,
-                                            uint32_t max_steps) {
+                                            uint32_t max_steps, Rep rep) {
+    float len = 0.0f;
+    uint32_t it = 0;
+    if (ALG == 1) {  // every SDF every step; the radius is taken after the step
+        while (len < render_dist) {
+            if (max_steps && it++ >= max_steps) break;
+            const v3 position = fma3(step, len, origin);
+            float dist = sphere_sdf<REP>(position, sph[0], rep);
+#pragma unroll
+            for (int i = 1; i < N; i++) dist = fmin_(dist, sphere_sdf<REP>(position, sph[i], rep));
+            len += dist;
+            const float radius = (len + 1.0f) * threshold;
+            if (dist <= radius) {
+                len -= radius;
+                break;
+            }
+        }
+        return len;
+    }
     float distances[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) distances[i] = sphere_sdf(origin, sph[i]);  // :37-39
-
-    float len = 0.0f, last = 0.0f;
-    uint32_t it = 0;
+    for (int i = 0; i < N; i++) distances[i] = sphere_sdf<REP>(origin, sph[i], rep);  // :37-39
+    if (ALG == 2) {  // one SDF per step: the object with the smallest cached bound, at the loop-top position
+        uint32_t closest = 0;
+        float nearest = 0.0f;
+        float dc = distances[0];  // distances[closest], kept current (no dynamically indexed register array)
+        while (len < render_dist) {
+            if (max_steps && it++ >= max_steps) break;
+            const v3 position = fma3(step, len, origin);
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                distances[i] -= nearest;
+                if ((uint32_t)i == closest) dc = distances[i];
+                if (distances[i] < dc) {
+                    closest = (uint32_t)i;
+                    dc = distances[i];
+                }
+            }
+            nearest = dc;
+            len += nearest;
+            float4 sc = sph[0];
+#pragma unroll
+            for (int i = 1; i < N; i++)
+                if ((uint32_t)i == closest) sc = sph[i];
+            dc = sphere_sdf<REP>(position, sc, rep);
+#pragma unroll
+            for (int i = 0; i < N; i++)
+                if ((uint32_t)i == closest) distances[i] = dc;
+            const float radius = (len + 1.0f) * threshold;
+            if (dc <= radius) {
+                len += dc - radius;
+                break;
+            }
+        }
+        return len;
+    }
+    float last = 0.0f;
     while (len < render_dist) {  // :44
         if (max_steps && it++ >= max_steps) break;
         const v3 position = fma3(step, len, origin);    // :45
@@ -49,7 +119,7 @@ __device__ __forceinline__ float trace_cone(const float4 (&sph)[RT_MAX_OBJECTS],
             // kept as a branch: evaluating all N distances and selecting (more ILP) was measured 1.5x
             // slower - the correctly rounded sqrt sequences are not free
             distances[i] -= last;
-            if (distances[i] <= radius) distances[i] = sphere_sdf(position, sph[i]);
+            if (distances[i] <= radius) distances[i] = sphere_sdf<REP>(position, sph[i], rep);
             dist = fmin_(dist, distances[i]);
         }
         last = fmax_(dist, 0.0f);  // :59
@@ -65,9 +135,9 @@ __device__ __forceinline__ float trace_cone(const float4 (&sph)[RT_MAX_OBJECTS],
 // ---- shaders/compute.glsl:70-87 ---------------------------------------------------------------
 // One invocation of compute.glsl:main for level pixel (gx, gy); `len0` is 1.0 at level 0 (:79) or the
 // parent texel (:80-82).
-template <int N>
+template <int N, int ALG = 3, bool REP = false>
 __device__ __forceinline__ float cone_pixel(const float4 (&sph)[RT_MAX_OBJECTS], const Camera cam, float isx, float isy, uint32_t gx, uint32_t gy, float len0,
-                                            float render_dist, uint32_t max_steps) {
+                                            float render_dist, uint32_t max_steps, Rep rep = Rep{0.0f, 0.0f, 0.0f}) {
     // :71-72  (gid*2 + 1) * imageSize - 1, then * ratio   (jitter = 0 for the reference's sample)
     float nx = __builtin_fmaf((float)(gx * 2u + 1u), isx, -1.0f) + cam.jitter[0];
     float ny = __builtin_fmaf((float)(gy * 2u + 1u), isy, -1.0f) + cam.jitter[1];
@@ -76,11 +146,11 @@ __device__ __forceinline__ float cone_pixel(const float4 (&sph)[RT_MAX_OBJECTS],
     const float threshold = (1.4142135f * 8.0f) * isx;  // :75
     const v3 step = normalize(rotate_q(cam.rot[0], cam.rot[1], cam.rot[2], cam.rot[3], mk(nx, 1.0f, ny)));  // :77
     const v3 pos = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
-    const float len = len0 + trace_cone<N>(sph, fma3(step, len0, pos), step, threshold, render_dist, max_steps);  // :84
+    const float len = len0 + trace_cone<N, ALG, REP>(sph, fma3(step, len0, pos), step, threshold, render_dist, max_steps, rep);  // :84
     return fmax_(len, 0.0f);                                                                                    // :86
 }
 
-template <int N>
+template <int N, int ALG, bool REP>
 __global__ __launch_bounds__(256) void cone_level_kernel(const SphereSet S, const ConeLevelParams p,
                                                          const float* __restrict__ parent, float* __restrict__ out) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -97,16 +167,17 @@ __global__ __launch_bounds__(256) void cone_level_kernel(const SphereSet S, cons
     Camera cam = p.cam;
     sample_jitter(p.sample0 + b, p.n_strata, p.width, p.height, &cam.jitter[0], &cam.jitter[1]);
     const float len0 = p.level > 0 ? parent[(size_t)b * p.parent_stride + (size_t)(gy >> 1) * p.parent_w + (gx >> 1)] : 1.0f;  // :79-82
-    out[(size_t)b * p.level_stride + (size_t)gy * p.w + gx] = cone_pixel<N>(S.s, cam, p.image_size[0], p.image_size[1], gx, gy, len0, p.render_dist, p.max_steps);
+    out[(size_t)b * p.level_stride + (size_t)gy * p.w + gx] = cone_pixel<N, ALG, REP>(S.s, cam, p.image_size[0], p.image_size[1], gx, gy, len0, p.render_dist, p.max_steps,
+                                                                              Rep{p.repeat[0], p.repeat[1], p.repeat[2]});
 }
 
 // ---- shaders/fragment.glsl:89-121 -------------------------------------------------------------
-template <int N>
+template <int N, bool REP>
 __device__ __forceinline__ float shadow_ray(const float4 (&sphere)[RT_MAX_OBJECTS], v3 origin, v3 step, float end,
-                                            float ray_radius, uint32_t max_steps) {
+                                            float ray_radius, uint32_t max_steps, Rep rep) {
     float distances[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) distances[i] = sphere_sdf(origin, sphere[i]);  // :92-94
+    for (int i = 0; i < N; i++) distances[i] = sphere_sdf<REP>(origin, sphere[i], rep);  // :92-94
 
     float last = 0.0f, nearest = 1.0f;  // :96-97
     uint32_t it = 0;
@@ -117,7 +188,7 @@ __device__ __forceinline__ float shadow_ray(const float4 (&sphere)[RT_MAX_OBJECT
 #pragma unroll
         for (int i = 0; i < N; i++) {  // :105-111
             distances[i] -= last;
-            if (distances[i] <= nearest) distances[i] = sphere_sdf(position, sphere[i]);
+            if (distances[i] <= nearest) distances[i] = sphere_sdf<REP>(position, sphere[i], rep);
             dist = fmin_(dist, distances[i]);
         }
         if (dist <= ray_radius) return 0.0f;  // :113-115
@@ -143,7 +214,7 @@ __device__ __forceinline__ float4 pick8(const float4 (&a)[8], uint32_t i) {
 // ---- shaders/fragment.glsl:127-187 ------------------------------------------------------------
 // One invocation of fragment.glsl:main for full-resolution pixel (px, py) whose depth is total_dist.
 // Returns true for a hit pixel; rgb = 0 for a miss (:137-140).
-template <int N>
+template <int N, bool REP>
 __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams p, float jx, float jy, uint32_t px, uint32_t py, float total_dist, float& r,
                                             float& g, float& b) {
     r = g = b = 0.0f;
@@ -158,13 +229,14 @@ __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams 
     const v3 position = fma3(step, total_dist, pos);  // :142
 
     // :144-156 nearest sphere (strict '<', first wins ties); material index = object index
-    float dist = sphere_sdf(position, S.sphere[0]);
+    const Rep rep{p.repeat[0], p.repeat[1], p.repeat[2]};
+    float dist = sphere_sdf<REP>(position, S.sphere[0], rep);
     float4 obj = S.sphere[0];
     float4 mat = S.mat_color_ambient[0];
     float shine = S.mat_shine[0];
 #pragma unroll
     for (int i = 1; i < N; i++) {
-        const float nd = sphere_sdf(position, S.sphere[i]);
+        const float nd = sphere_sdf<REP>(position, S.sphere[i], rep);
         if (nd < dist) {
             dist = nd;
             obj = S.sphere[i];
@@ -175,7 +247,7 @@ __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams 
 
     const float cam_dist = length(position - pos);                                                    // :162
     const float cam_fall = fmax_(p.cam_fall_off * __builtin_fmaf(cam_dist, cam_dist, 1.0f), 1.0f);   // :163
-    const v3 normal = normalize(position - mk(obj.x, obj.y, obj.z));                                  // :166
+    const v3 normal = normalize(domain<REP>(position, rep) - mk(obj.x, obj.y, obj.z));                // :166
     const v3 cam_dir = -step;
     const float normal_fall = fmax_(dot(normal, cam_dir), 0.0f);  // :167
 
@@ -184,7 +256,7 @@ __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams 
         const v3 lpos = mk(lp.x, lp.y, lp.z);
         const v3 light_dir = normalize(lpos - position);   // :173
         const float light_dist = length(position - lpos);  // :174
-        const float soft = fmin_(shadow_ray<N>(S.sphere, position + light_dir, light_dir, light_dist, p.ray_radius, p.max_steps), 1.0f);  // :176
+        const float soft = fmin_(shadow_ray<N, REP>(S.sphere, position + light_dir, light_dir, light_dist, p.ray_radius, p.max_steps, rep), 1.0f);  // :176
         const float light_fall = fmax_((p.light_fall_off * light_dist) * light_dist, 1.0f);                                               // :178
         const float diffuse = fmax_(dot(normal, light_dir), 0.0f);                                                                        // :180
         // :181, :47-50  reflect(I,N) = I - 2*dot(N,I)*N with I = -lightDir
@@ -207,7 +279,7 @@ __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams 
 }
 
 // Grid: 16 workgroups per owned framebuffer tile; every wave shades one 8x8 block of the tile.
-template <int N>
+template <int N, bool REP>
 __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const ShadeParams p, const float* __restrict__ depth,
                                                     float* __restrict__ dst, uint64_t* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -234,7 +306,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
     for (uint32_t sb = 0; sb < p.n_batch; sb++) {
         float jx, jy, sr, sg, sbl;
         sample_jitter(p.sample0 + sb, p.n_strata, p.width, p.height, &jx, &jy);
-        const bool hit = inside && shade_pixel<N>(S, p, jx, jy, px, py, depth[(size_t)sb * p.depth_stride + (size_t)py * p.depth_w + px], sr, sg, sbl);  // :135
+        const bool hit = inside && shade_pixel<N, REP>(S, p, jx, jy, px, py, depth[(size_t)sb * p.depth_stride + (size_t)py * p.depth_w + px], sr, sg, sbl);  // :135
         if (have_sum) {
             r += sr;
             g += sg;
@@ -369,18 +441,32 @@ __global__ __launch_bounds__(256) void to_rgba8_kernel(const float* __restrict__
 // ---- launchers ----------------------------------------------------------------------------------
 template <int N>
 static void cone_launch_n(hipStream_t st, dim3 grid, const SphereSet& S, const ConeLevelParams& p, const float* parent, float* out) {
-    hipLaunchKernelGGL(cone_level_kernel<N>, grid, dim3(256), 0, st, S, p, parent, out);
+    const bool rep = p.repeat[0] > 0.0f || p.repeat[1] > 0.0f || p.repeat[2] > 0.0f;
+    // the reference as shipped (algorithm 3, no repetition) first; the sketched variants behind it
+    if (p.alg == 1) {
+        if (rep) hipLaunchKernelGGL((cone_level_kernel<N, 1, true>), grid, dim3(256), 0, st, S, p, parent, out);
+        else hipLaunchKernelGGL((cone_level_kernel<N, 1, false>), grid, dim3(256), 0, st, S, p, parent, out);
+    } else if (p.alg == 2) {
+        if (rep) hipLaunchKernelGGL((cone_level_kernel<N, 2, true>), grid, dim3(256), 0, st, S, p, parent, out);
+        else hipLaunchKernelGGL((cone_level_kernel<N, 2, false>), grid, dim3(256), 0, st, S, p, parent, out);
+    } else if (rep) {
+        hipLaunchKernelGGL((cone_level_kernel<N, 3, true>), grid, dim3(256), 0, st, S, p, parent, out);
+    } else {
+        hipLaunchKernelGGL((cone_level_kernel<N, 3, false>), grid, dim3(256), 0, st, S, p, parent, out);
+    }
 }
 template <int N>
 static void shade_launch_n(hipStream_t st, dim3 grid, const ShadeSet& S, const ShadeParams& p, const float* depth, float* dst,
                            uint64_t* counters) {
-    hipLaunchKernelGGL(shade_kernel<N>, grid, dim3(256), 0, st, S, p, depth, dst, counters);
+    if (p.repeat[0] > 0.0f || p.repeat[1] > 0.0f || p.repeat[2] > 0.0f) hipLaunchKernelGGL((shade_kernel<N, true>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
+    else hipLaunchKernelGGL((shade_kernel<N, false>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
 }
 
 int launch_cone_level(Ctx* c, const SphereSet& S, uint32_t n_obj, const ConeLevelParams& p, const float* parent, float* out, uint32_t batch) {
     if (n_obj < 1 || n_obj > RT_MAX_OBJECTS) return c->fail(RT_ERR_INVALID, "objCount %u out of [1,8]", n_obj);
     if ((p.w & 7u) || (p.h & 7u) || p.w == 0 || p.h == 0) return c->fail(RT_ERR_INVALID, "level dims %ux%u not multiples of 8", p.w, p.h);
     if (batch < 1 || batch > 65535u || p.n_strata < 1) return c->fail(RT_ERR_INVALID, "sample batch %u / strata %u", batch, p.n_strata);
+    if (p.alg != 1 && p.alg != 2 && p.alg != 3) return c->fail(RT_ERR_INVALID, "march algorithm %u", p.alg);
     if (p.level > 0 && (parent == nullptr || p.parent_w * 2u < p.w)) return c->fail(RT_ERR_INVALID, "level %u: bad parent image", p.level);
     const uint32_t tiles = (p.w >> 3) * (p.h >> 3);
     const dim3 grid((tiles + 3u) / 4u, batch);

@@ -164,6 +164,8 @@ int enqueue_samples(Ctx* c, const float rot[4], const float pos[3], uint32_t s0,
             p.n_strata = n_strata;
             p.level_stride = c->dims[i][0] * c->dims[i][1];
             p.parent_stride = i ? c->dims[i - 1][0] * c->dims[i - 1][1] : 0;
+            p.alg = c->cfg.march_algorithm ? c->cfg.march_algorithm : 3u;
+            std::memcpy(p.repeat, c->cfg.repeat, sizeof p.repeat);
             if (stage_events) RT_HIP(c, hipEventRecord(c->ev_stage[ev++], c->stream));
             int rc = rt::launch_cone_level(c, spheres, c->scene.objCount, p, i ? c->d_level[i - 1] : nullptr, c->d_level[i], nb);
             if (rc) return rc;
@@ -193,6 +195,7 @@ int enqueue_samples(Ctx* c, const float rot[4], const float pos[3], uint32_t s0,
     sp.n_batch = nb;
     sp.n_strata = n_strata;
     sp.depth_stride = c->dims[count - 1][0] * c->dims[count - 1][1];
+    std::memcpy(sp.repeat, c->cfg.repeat, sizeof sp.repeat);
     int rc = rt::launch_shade(c, set, c->scene.objCount, sp, c->d_level[count - 1], dst, c->d_counters);
     if (rc) return rc;
     if (stage_events) RT_HIP(c, hipEventRecord(c->ev_stage[ev++], c->stream));
@@ -290,6 +293,8 @@ int rt_default_config(rt_config* cfg) {
     cfg->max_steps = 1u << 20;
     cfg->profile_stages = 0;
     cfg->fuse_levels = 0;  // measured slower than one launch per level (path_a.hip)
+    cfg->march_algorithm = 0;
+    cfg->repeat[0] = cfg->repeat[1] = cfg->repeat[2] = 0.0f;
     return RT_OK;
 }
 
@@ -388,6 +393,11 @@ int rt_set_config(rt_ctx* ctx, const rt_config* cfg) {
     if (!c) return RT_ERR_INVALID;
     if (!cfg) return c->fail(RT_ERR_INVALID, "cfg is NULL");
     if (!(cfg->render_dist > 0.0f) || !(cfg->ray_radius > 0.0f)) return c->fail(RT_ERR_INVALID, "render_dist and ray_radius must be > 0");
+    if (cfg->march_algorithm > 3) return c->fail(RT_ERR_INVALID, "march_algorithm %u (0..3)", cfg->march_algorithm);
+    const bool variant = (cfg->march_algorithm != 0 && cfg->march_algorithm != 3) || cfg->repeat[0] > 0.0f || cfg->repeat[1] > 0.0f || cfg->repeat[2] > 0.0f;
+    for (float r : cfg->repeat)
+        if (!(r >= 0.0f) || !(r < 3.0e38f)) return c->fail(RT_ERR_INVALID, "repeat periods must be finite and >= 0");
+    if (variant && cfg->fuse_levels) return c->fail(RT_ERR_INVALID, "march_algorithm / repeat need fuse_levels = 0");
     c->cfg = *cfg;
     return RT_OK;
 }

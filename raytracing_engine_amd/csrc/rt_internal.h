@@ -64,6 +64,8 @@ struct ConeLevelParams {
     // into image b of the level (images level_stride floats apart; parents parent_stride apart)
     uint32_t sample0, n_strata;
     uint32_t level_stride, parent_stride;
+    uint32_t alg;     // march loop body: 3 = compute.glsl:46-65, 1 / 2 = tracing_algorithms.txt:2-13 / :16-37
+    float repeat[3];  // > 0: domain repetition period on that axis (utilities.glsl:31-34)
 };
 
 struct ShadeParams {
@@ -81,6 +83,7 @@ struct ShadeParams {
     // order (depth image b is depth_stride floats after image 0) and adds them in that order
     uint32_t sample0, n_batch, n_strata;
     uint32_t depth_stride;
+    float repeat[3];  // > 0: domain repetition period on that axis (utilities.glsl:31-34)
 };
 
 // Sub-pixel offset of sample s of an n x n stratified pixel in NDC: the stratum centre (i + 0.5)/n inside

@@ -18,11 +18,17 @@ from raytracing_engine_amd import host  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def case(name, scene_bytes, w, h, rot, pos):
+def case(name, scene_bytes, w, h, rot, pos, march_algorithm=0, repeat=(0.0, 0.0, 0.0), max_steps=None):
     scene = O.scene_from_bytes(scene_bytes)
-    r = O.render_a(scene, w, h, rot=rot, pos=pos)
+    cfg = O.default_config()
+    cfg.march_algorithm = march_algorithm
+    cfg.repeat[:] = repeat
+    if max_steps:
+        cfg.max_steps = max_steps
+    r = O.render_a(scene, w, h, rot=rot, pos=pos, cfg=cfg)
     out = {"scene": np.frombuffer(scene_bytes, np.uint8), "width": w, "height": h,
            "rot": np.asarray(rot, np.float32), "pos": np.asarray(pos, np.float32), "rgb": r["rgb"],
+           "march_algorithm": march_algorithm, "repeat": np.asarray(repeat, np.float32), "max_steps": int(cfg.max_steps),
            "counters": np.array(list(r["counters"].values()), np.uint64)}
     for i, lv in enumerate(r["levels"]):
         out[f"level{i}"] = lv
@@ -34,3 +40,7 @@ if __name__ == "__main__":
     case("path_a_default_64.npz", bytes(host.default_scene()), 64, 64, (0, 0, 0, 1), (0, 0, 0))
     case("path_a_default_turn_96x64.npz", bytes(host.default_scene()), 96, 64, host.camera_quat(0.6, -0.2), (1.0, -2.0, 0.5))
     case("path_a_cornell_256.npz", bytes(host.cornell_scene()), 256, 256, (0, 0, 0, 1), (0, 0, 0))
+    # SDF feature growth: march algorithms 1 and 2, domain repetition
+    case("path_a_alg1_96x64.npz", bytes(host.default_scene()), 96, 64, host.camera_quat(0.3, -0.1), (0.5, -1.0, 0.2), march_algorithm=1, max_steps=4096)
+    case("path_a_alg2_96x64.npz", bytes(host.default_scene()), 96, 64, host.camera_quat(0.3, -0.1), (0.5, -1.0, 0.2), march_algorithm=2, max_steps=4096)
+    case("path_a_repeat_96x64.npz", bytes(host.default_scene()), 96, 64, host.camera_quat(0.3, -0.1), (0.5, -1.0, 0.2), repeat=(40.0, 0.0, 40.0), max_steps=4096)

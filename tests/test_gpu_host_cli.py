@@ -65,3 +65,20 @@ def test_soup_scene_path_traced(exe, tmp_path):
     v, a, e = scenes.soup_scene(5000, seed=1, edge=0.25)
     ref, _ = O.TriScene(v, a, e).render(96, 54, spp=2, bounces=1, seed=3, sky=(0.2, 0.2, 0.25))
     assert np.array_equal(read_pfm(out), ref)
+
+
+def test_sketched_variants_and_frames_in_flight(exe, tmp_path):
+    """--march / --repeat reach rt_config; --inflight runs the frame loop through the
+    fence-per-image slots (f.3) and must write the same picture as the synchronous loop."""
+    out = tmp_path / "v.pfm"
+    subprocess.run([exe, "--size", "160x96", "--march", "2", "--repeat", "40,0,40", "--out", str(out)], check=True)
+    cfg = O.default_config()
+    cfg.march_algorithm = 2
+    cfg.repeat[:] = (40.0, 0.0, 40.0)
+    ref = O.render_a(O.default_scene(), 160, 96, cfg=cfg)["rgb"]
+    assert np.abs(read_pfm(out) - ref).max() <= 1e-4
+    a, b = tmp_path / "sync.ppm", tmp_path / "slots.ppm"
+    subprocess.run([exe, "--size", "160x96", "--frames", "5", "--out", str(a)], check=True)
+    res = subprocess.run([exe, "--size", "160x96", "--frames", "5", "--inflight", "3", "--out", str(b)], check=True, capture_output=True, text=True)
+    assert "through 3 slots" in res.stdout
+    assert np.array_equal(read_ppm(a), read_ppm(b))

@@ -80,16 +80,23 @@ def test_camera_poses(renderer, yaw, pitch, pos):
     check_frame(renderer, R.default_scene(), 160, 96, rot=R.camera_quat(yaw, pitch), pos=pos)
 
 
-@pytest.mark.parametrize("name", ["path_a_default_64.npz", "path_a_default_turn_96x64.npz", "path_a_cornell_256.npz"])
+@pytest.mark.parametrize("name", ["path_a_default_64.npz", "path_a_default_turn_96x64.npz", "path_a_cornell_256.npz",
+                                  "path_a_alg1_96x64.npz", "path_a_alg2_96x64.npz", "path_a_repeat_96x64.npz"])
 def test_against_committed_fixture(renderer, golden_dir, name):
     g = np.load(os.path.join(golden_dir, name))
     renderer.set_scene(g["scene"].tobytes())
     w, h = int(g["width"]), int(g["height"])
     renderer.resize(w, h)
     count = len(renderer.level_info())
+    variant = int(g["march_algorithm"]) != 0 or bool(np.any(g["repeat"] > 0))
     try:
-        for fused in (False, True):
-            set_fused(renderer, fused)
+        for fused in ((False,) if variant else (False, True)):  # the sketched variants exist in the per-level schedule only
+            cfg = renderer.default_config()
+            cfg.fuse_levels = int(fused)
+            cfg.march_algorithm = int(g["march_algorithm"])
+            cfg.repeat[:] = [float(v) for v in g["repeat"]]
+            cfg.max_steps = int(g["max_steps"])
+            renderer.set_config(cfg)
             rgb = renderer.render(g["rot"], g["pos"])
             for i in range(count):
                 got, want = renderer.read_level(i), g[f"level{i}"]
@@ -136,6 +143,66 @@ def test_config_is_honoured(renderer):
             assert np.abs(rgb - ref["rgb"]).max() <= RGB_TOL
     finally:
         renderer.set_config(renderer.default_config())
+
+
+@pytest.mark.parametrize("alg", [1, 2, 3])
+@pytest.mark.parametrize("repeat", [(0.0, 0.0, 0.0), (40.0, 0.0, 40.0), (9.0, 50.0, 0.0)])
+@pytest.mark.parametrize("n_obj", [4, 8])
+def test_sketched_variants(renderer, alg, repeat, n_obj):
+    """march algorithms 1 / 2 (shaders/tracing_algorithms.txt) and repeat()
+    (utilities.glsl:31-34) against the oracle's restatement: depth pyramid bit-exact, RGB <= 1e-4."""
+    scene = R.default_scene() if n_obj == 4 else R.cornell_scene()
+    w, h = 200, 120
+    rot, pos = host.camera_quat(0.3, -0.1), (0.5, -1.0, 0.2)
+    ocfg = O.default_config()
+    ocfg.march_algorithm, ocfg.max_steps = alg, 4096
+    ocfg.repeat[:] = repeat
+    ref = O.render_a(oracle_scene(scene), w, h, rot=rot, pos=pos, cfg=ocfg)
+    try:
+        cfg = renderer.default_config()
+        cfg.march_algorithm, cfg.max_steps = alg, 4096
+        cfg.repeat[:] = repeat
+        renderer.set_config(cfg)
+        renderer.set_scene(scene)
+        renderer.resize(w, h)
+        rgb = renderer.render(rot, pos)
+        for i, lv in enumerate(ref["levels"]):
+            got = renderer.read_level(i)
+            assert np.array_equal(got, lv), f"level {i}: {np.count_nonzero(got != lv)} texels differ"
+        assert np.abs(rgb - ref["rgb"]).max() <= RGB_TOL
+        assert renderer.stats()["hit_pixels"] == ref["counters"]["hit_pixels"]
+        # 4 spp through the batched launches == the four jittered oracle frames in index order
+        rgb4 = renderer.render(rot, pos, spp=4)
+        acc = None
+        for s in range(4):
+            i, j = s % 2, s // 2
+            jit = (((np.float32(2 * i + 1) / np.float32(2)) - np.float32(1)) / np.float32(w),
+                   ((np.float32(2 * j + 1) / np.float32(2)) - np.float32(1)) / np.float32(h))
+            f = O.render_a(oracle_scene(scene), w, h, rot=rot, pos=pos, jitter=jit, cfg=ocfg, want_levels=False)["rgb"]
+            acc = f if acc is None else acc + f
+        assert np.abs(rgb4 - acc / np.float32(4)).max() <= RGB_TOL
+    finally:
+        renderer.set_config(renderer.default_config())
+
+
+def test_sketched_variants_error_behaviour(renderer):
+    cfg = renderer.default_config()
+    cfg.march_algorithm = 4
+    with pytest.raises(R.RtError):
+        renderer.set_config(cfg)
+    cfg = renderer.default_config()
+    cfg.march_algorithm, cfg.fuse_levels = 1, 1
+    with pytest.raises(R.RtError):
+        renderer.set_config(cfg)
+    cfg = renderer.default_config()
+    cfg.repeat[0] = -1.0
+    with pytest.raises(R.RtError):
+        renderer.set_config(cfg)
+    cfg = renderer.default_config()
+    cfg.repeat[2], cfg.fuse_levels = 8.0, 1
+    with pytest.raises(R.RtError):
+        renderer.set_config(cfg)
+    renderer.set_config(renderer.default_config())
 
 
 def test_spp4_stratified(renderer):

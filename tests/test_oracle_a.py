@@ -224,16 +224,69 @@ def test_unorm8():
     assert out.tolist() == [[[0, 0, 128, 255], [255, 255, 255, 255]]]
 
 
-@pytest.mark.parametrize("name", ["path_a_default_64.npz", "path_a_default_turn_96x64.npz", "path_a_cornell_256.npz"])
+FIXTURES_A = ["path_a_default_64.npz", "path_a_default_turn_96x64.npz", "path_a_cornell_256.npz",
+              "path_a_alg1_96x64.npz", "path_a_alg2_96x64.npz", "path_a_repeat_96x64.npz"]
+
+
+def fixture_config(g):
+    cfg = O.default_config()
+    cfg.march_algorithm = int(g["march_algorithm"])
+    cfg.repeat[:] = [float(v) for v in g["repeat"]]
+    cfg.max_steps = int(g["max_steps"])
+    return cfg
+
+
+@pytest.mark.parametrize("name", FIXTURES_A)
 def test_oracle_matches_committed_fixture(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name))
     sc = O.scene_from_bytes(g["scene"].tobytes())
-    r = O.render_a(sc, int(g["width"]), int(g["height"]), rot=g["rot"], pos=g["pos"])
+    r = O.render_a(sc, int(g["width"]), int(g["height"]), rot=g["rot"], pos=g["pos"], cfg=fixture_config(g))
     for i, lv in enumerate(r["levels"]):
         assert np.array_equal(lv, g[f"level{i}"]), f"level {i}"
     # powf is the only libm call in the path: allow its last-ulp variation across hosts
     np.testing.assert_allclose(r["rgb"], g["rgb"], rtol=0, atol=1e-6)
     assert list(r["counters"].values()) == g["counters"].tolist()
+
+
+# ---- SDF feature growth the author sketched -----------------------------------
+@pytest.mark.parametrize("alg", [1, 2])
+def test_sketched_march_algorithms_known_answer(alg):
+    """shaders/tracing_algorithms.txt:2-13 / :16-37 by hand for one sphere straight ahead (centre 10 away,
+    radius 2): both reach the surface at len = 8 with SDF 0 and stop with len = 8 - (8 + 1) * threshold.
+    Algorithm 2 needs one more iteration: its first refresh is taken at the loop-top position."""
+    f = np.float32
+    sc = one_sphere((0.0, 10.0, 0.0), 2.0)
+    cfg = O.default_config()
+    cfg.march_algorithm = alg
+    t = f(0.01)
+    want = f(8.0) - (f(8.0) + f(1.0)) * t
+    assert f(O.trace_cone(sc, (0, 0, 0), (0, 1, 0), float(t), cfg=cfg)) == want
+
+
+def test_algorithm1_is_the_bruteforce_listing():
+    sc = O.scene_from_bytes(bytes(host.default_scene()))
+    cfg = O.default_config()
+    cfg.march_algorithm = 1
+    for d in [(0, 1, 0), (0.3, 0.9, -0.1), (-0.6, 0.7, 0.2)]:
+        d = np.asarray(d, np.float32) / np.float32(np.linalg.norm(d))
+        assert O.trace_cone(sc, (0, 0, 0), d, 0.02, cfg=cfg) == O.trace_cone(sc, (0, 0, 0), d, 0.02, brute=True)
+
+
+def test_domain_repetition_known_answer():
+    """utilities.glsl:31-34: a sphere of radius 1 at the origin repeated every 8 units along y; a ray from
+    y = 2 along +y meets the copy at y = 8 (surface at 7): len = 5 - radius term.  Without repetition it
+    leaves the scene."""
+    f = np.float32
+    sc = one_sphere((0.0, 0.0, 0.0), 1.0)
+    cfg = O.default_config()
+    assert O.trace_cone(sc, (0, 2, 0), (0, 1, 0), 0.01, cfg=cfg) >= cfg.render_dist
+    cfg.repeat[1] = 8.0
+    got = f(O.trace_cone(sc, (0, 2, 0), (0, 1, 0), 0.01, cfg=cfg))
+    # algorithm 3: first step 1 (SDF at y=2 in the repeated domain), ... the exact chain is arithmetic in f32;
+    # the hit distance is within one cone radius of the surface of the copy
+    assert 5.0 - (5.0 + 1.0) * 0.011 <= got <= 5.0
+    # periodicity: starting one period later gives the same answer
+    assert f(O.trace_cone(sc, (0, 10, 0), (0, 1, 0), 0.01, cfg=cfg)) == got
 
 
 def test_default_scene_matches_reference_listing():
