@@ -211,3 +211,30 @@ def test_shadow_overlap_does_not_change_results(renderer):
     one = renderer.render_pt(pos=(0, 1, 0), spp=3, bounces=3, seed=8)
     two = renderer.render_pt(pos=(0, 1, 0), spp=3, bounces=3, seed=8, tune_no_overlap=1)
     assert np.array_equal(one, two)
+
+
+@pytest.mark.parametrize("knobs", [dict(tune_refill_min=1), dict(tune_refill_min=64), dict(tune_refill_min=8 | (3 << 8)), dict(tune_blocks_per_cu=1),
+                                   dict(tune_blocks_per_cu=3, tune_lds_stack=2), dict(tune_lds_stack=1), dict(tune_lds_stack=40)])
+def test_scheduling_knobs_do_not_change_the_frame(renderer, knobs):
+    """Refill threshold, triangle tests per round, resident workgroups, LDS / spill split of the traversal
+    stack: pure scheduling, so the frame and the ray counts must be identical to the default's."""
+    v, a, e = scenes.soup_scene(30000, seed=9, edge=0.6)
+    renderer.set_mesh(v, a, e)
+    renderer.resize(160, 96)
+    base = renderer.render_pt(spp=2, bounces=2, seed=5, sky=(0.2, 0.2, 0.25))
+    st0 = renderer.pt_stats()
+    got = renderer.render_pt(spp=2, bounces=2, seed=5, sky=(0.2, 0.2, 0.25), **knobs)
+    st1 = renderer.pt_stats()
+    assert np.array_equal(base, got)
+    assert st1["stack_overflow"] == 0
+    for k in ("camera_rays", "bounce_rays", "shadow_rays"):
+        assert st0[k] == st1[k]
+
+
+def test_queue_streams_cover_every_entry_exactly_once(renderer):
+    """The ray queue is consumed through 16 interleaved stream heads (64-entry blocks); queue lengths
+    around the block / stream boundaries must neither drop nor repeat an entry: the frame equals the
+    oracle's for views of 1 .. a few thousand paths."""
+    mesh = scenes.cornell_tri_scene()
+    for w, h in [(1, 1), (7, 9), (8, 8), (63, 1), (64, 1), (65, 1), (32, 32), (1023, 1), (1025, 1), (129, 17)]:
+        check_pt(renderer, mesh, w, h, pos=(0, 1, 0), spp=1, bounces=2, seed=w * 31 + h)
