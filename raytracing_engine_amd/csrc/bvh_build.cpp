@@ -12,13 +12,54 @@
 // Layout: bvh_build.h.
 #include "bvh_build.h"
 
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
+
+#ifdef RT_BVH_TIMING
+#include <chrono>
+#include <cstdio>
+#define RT_BVH_T(x) const auto x = std::chrono::steady_clock::now()
+#define RT_BVH_REPORT(what, a, b) std::fprintf(stderr, "bvh: %-18s %8.1f ms\n", what, std::chrono::duration<double, std::milli>((b) - (a)).count())
+#else
+#define RT_BVH_T(x) (void)0
+#define RT_BVH_REPORT(what, a, b) (void)0
+#endif
 
 namespace rt {
 namespace {
+
+// CPUs this process may run on (the GPU boxes grant a slice of the machine), at most 32
+int host_threads() {
+    cpu_set_t set;
+    int n = 1;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    return std::min(std::max(n, 1), 32);
+}
+
+// fn(i) for i in [0, n) on up to `threads` threads (contiguous chunks; fn must only touch item i's data)
+template <typename F>
+void parallel_for(size_t n, int threads, size_t kMinPerThread, F fn) {
+    const size_t want = std::min<size_t>((size_t)std::max(threads, 1), (n + kMinPerThread - 1) / kMinPerThread);
+    if (want <= 1) {
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(want - 1);
+    const size_t chunk = (n + want - 1) / want;
+    for (size_t t = 1; t < want; t++)
+        pool.emplace_back([=, &fn] {
+            for (size_t i = t * chunk; i < std::min(n, (t + 1) * chunk); i++) fn(i);
+        });
+    for (size_t i = 0; i < std::min(n, chunk); i++) fn(i);
+    for (auto& th : pool) th.join();
+}
 
 struct Box {
     float lo[3], hi[3];
@@ -56,8 +97,17 @@ struct Builder {
     float pad;
     uint32_t max_depth;
     uint32_t kLeafMax = 4;
-    uint32_t depth_reached = 0;
-    double sah = 0.0;
+    // Subtrees are independent (disjoint ranges of `order`, disjoint node indices: with single-triangle
+    // leaves a range of `count` triangles owns exactly count - 1 nodes, numbered in preorder), so big
+    // ones are built by their own threads.  Results do not depend on the thread count.
+    std::atomic<int>* spare_threads = nullptr;
+    int n_threads = 1;
+
+    struct Sub {
+        int32_t ref;
+        uint32_t depth_reached;
+        double sah;
+    };
 
     Box range_box(uint32_t first, uint32_t count) const {
         Box b;
@@ -79,24 +129,52 @@ struct Builder {
         return d;
     }
 
-    // returns child ref; depth = depth of the node that would be created
-    int32_t build(uint32_t first, uint32_t count, uint32_t depth) {
-        if (count <= kLeafMax) return leaf_ref(first, count);
-        depth_reached = std::max(depth_reached, depth);
-        const uint32_t me = (uint32_t)(nodes.size() / 16);
-        nodes.resize(nodes.size() + 16);
+    // returns child ref; depth = depth of the node that would be created; `me` = its node index
+    // (kLeafMax == 1: preorder numbering, the left subtree takes me + 1 .. me + mid - 1, the right one starts at me + mid)
+    Sub build(uint32_t first, uint32_t count, uint32_t depth, uint32_t me) {
+        if (count <= kLeafMax) return Sub{leaf_ref(first, count), 0u, 0.0};
 
-        // centroid bounds
+        // centroid bounds (big nodes: in parallel chunks; min / max do not depend on the order)
+        const int par = count >= kParallelBinMin ? n_threads : 1;
+        const size_t n_chunks = (size_t)std::max(par, 1);
+        const uint32_t chunk = (uint32_t)((count + n_chunks - 1) / n_chunks);
         float clo[3], chi[3];
-        for (int a = 0; a < 3; a++) {
-            clo[a] = std::numeric_limits<float>::infinity();
-            chi[a] = -clo[a];
-        }
-        for (uint32_t i = 0; i < count; i++) {
-            const float* c = &centroid[3 * (size_t)order[first + i]];
+        {
+            // (no heap traffic for the many small nodes: one chunk lives on the stack)
+            float one_lo[3], one_hi[3];
+            std::vector<float> many_lo, many_hi;
+            if (n_chunks > 1) {
+                many_lo.resize(3 * n_chunks);
+                many_hi.resize(3 * n_chunks);
+            }
+            float* plo = n_chunks > 1 ? many_lo.data() : one_lo;
+            float* phi = n_chunks > 1 ? many_hi.data() : one_hi;
+            for (size_t i = 0; i < 3 * n_chunks; i++) {
+                plo[i] = std::numeric_limits<float>::infinity();
+                phi[i] = -std::numeric_limits<float>::infinity();
+            }
+            parallel_for(n_chunks, par, 1, [&](size_t c) {
+                float lo[3] = {plo[3 * c], plo[3 * c + 1], plo[3 * c + 2]}, hi[3] = {phi[3 * c], phi[3 * c + 1], phi[3 * c + 2]};
+                const uint32_t i1 = std::min<uint32_t>(count, (uint32_t)(c + 1) * chunk);
+                for (uint32_t i = (uint32_t)c * chunk; i < i1; i++) {
+                    const float* ce = &centroid[3 * (size_t)order[first + i]];
+                    for (int a = 0; a < 3; a++) {
+                        lo[a] = std::min(lo[a], ce[a]);
+                        hi[a] = std::max(hi[a], ce[a]);
+                    }
+                }
+                for (int a = 0; a < 3; a++) {
+                    plo[3 * c + a] = lo[a];
+                    phi[3 * c + a] = hi[a];
+                }
+            });
             for (int a = 0; a < 3; a++) {
-                clo[a] = std::min(clo[a], c[a]);
-                chi[a] = std::max(chi[a], c[a]);
+                clo[a] = plo[a];
+                chi[a] = phi[a];
+                for (size_t c = 1; c < n_chunks; c++) {
+                    clo[a] = std::min(clo[a], plo[3 * c + a]);
+                    chi[a] = std::max(chi[a], phi[3 * c + a]);
+                }
             }
         }
 
@@ -106,19 +184,48 @@ struct Builder {
         if (!must_balance) {
             float best_cost = std::numeric_limits<float>::infinity();
             int best_axis = -1, best_bin = -1;
-            for (int a = 0; a < 3; a++) {
-                const float ext = chi[a] - clo[a];
-                if (!(ext > 0.0f)) continue;
-                const float k = (float)kBins / ext;
-                Box bb[kBins];
-                uint32_t bc[kBins] = {};
-                for (auto& b : bb) b.reset();
-                for (uint32_t i = 0; i < count; i++) {
+            // all three axes binned in one pass over the triangles (per chunk, then merged: box unions and counts
+            // are order independent)
+            struct Bins {
+                Box bb[3][kBins];
+                uint32_t bc[3][kBins];
+            };
+            Bins one_part;
+            std::vector<Bins> many_part;
+            if (n_chunks > 1) many_part.resize(n_chunks);
+            Bins* part = n_chunks > 1 ? many_part.data() : &one_part;
+            float kk[3];
+            for (int a = 0; a < 3; a++) kk[a] = chi[a] - clo[a] > 0.0f ? (float)kBins / (chi[a] - clo[a]) : 0.0f;
+            parallel_for(n_chunks, par, 1, [&](size_t c) {
+                Bins& P = part[c];
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < kBins; b++) {
+                        P.bb[a][b].reset();
+                        P.bc[a][b] = 0;
+                    }
+                const uint32_t i1 = std::min<uint32_t>(count, (uint32_t)(c + 1) * chunk);
+                for (uint32_t i = (uint32_t)c * chunk; i < i1; i++) {
                     const uint32_t t = order[first + i];
-                    int bin = (int)((centroid[3 * (size_t)t + a] - clo[a]) * k);
-                    bin = std::min(std::max(bin, 0), kBins - 1);
-                    bb[bin].grow(tri_box[t]);
-                    bc[bin]++;
+                    for (int a = 0; a < 3; a++) {
+                        if (!(kk[a] > 0.0f)) continue;
+                        int bin = (int)((centroid[3 * (size_t)t + a] - clo[a]) * kk[a]);
+                        bin = std::min(std::max(bin, 0), kBins - 1);
+                        P.bb[a][bin].grow(tri_box[t]);
+                        P.bc[a][bin]++;
+                    }
+                }
+            });
+            for (int a = 0; a < 3; a++) {
+                if (!(kk[a] > 0.0f)) continue;
+                Box bb[kBins];
+                uint32_t bc[kBins];
+                for (int b = 0; b < kBins; b++) {
+                    bb[b] = part[0].bb[a][b];
+                    bc[b] = part[0].bc[a][b];
+                    for (size_t c = 1; c < n_chunks; c++) {
+                        bb[b].grow(part[c].bb[a][b]);
+                        bc[b] += part[c].bc[a][b];
+                    }
                 }
                 float right_area[kBins];
                 uint32_t right_cnt[kBins];
@@ -171,9 +278,22 @@ struct Builder {
         }
 
         Box b0 = range_box(first, mid), b1 = range_box(first + mid, count - mid);
-        sah += (double)b0.half_area() + (double)b1.half_area();
-        const int32_t r0 = build(first, mid, depth + 1);
-        const int32_t r1 = build(first + mid, count - mid, depth + 1);
+        Sub s0, s1;
+        bool forked = false;
+        if (spare_threads && count >= kForkMin && spare_threads->fetch_sub(1) > 0) {
+            forked = true;
+            std::thread left([&] { s0 = build(first, mid, depth + 1, me + 1u); });
+            s1 = build(first + mid, count - mid, depth + 1, me + mid);
+            left.join();
+            spare_threads->fetch_add(1);
+        } else if (spare_threads && count >= kForkMin) {
+            spare_threads->fetch_add(1);  // undo the failed reservation
+        }
+        if (!forked) {
+            s0 = build(first, mid, depth + 1, me + 1u);
+            s1 = build(first + mid, count - mid, depth + 1, me + mid);
+        }
+        const int32_t r0 = s0.ref, r1 = s1.ref;
         float* n = &nodes[(size_t)me * 16];
         const float p = pad;
         n[0] = b0.lo[0] - p; n[1] = b0.lo[1] - p; n[2] = b0.lo[2] - p; n[3] = b0.hi[0] + p;
@@ -182,8 +302,12 @@ struct Builder {
         std::memcpy(&n[12], &r0, 4);
         std::memcpy(&n[13], &r1, 4);
         n[14] = n[15] = 0.0f;
-        return (int32_t)me;
+        // tree-shaped sums: the same value whatever the thread count
+        return Sub{(int32_t)me, std::max(depth, std::max(s0.depth_reached, s1.depth_reached)),
+                   ((double)b0.half_area() + (double)b1.half_area()) + (s0.sah + s1.sah)};
     }
+    static constexpr uint32_t kForkMin = 1u << 14;        // triangles below which a subtree is not worth a thread
+    static constexpr uint32_t kParallelBinMin = 1u << 17;  // triangles from which one node's binning is split over threads
 };
 
 }  // namespace
@@ -234,10 +358,47 @@ struct Cw8Builder {
         return r;
     }
 
+    // The binary nodes are numbered in preorder (a subtree is a contiguous index range, children have
+    // larger indices than their parent), so disjoint subtrees are solved by different threads and the few
+    // nodes above them afterwards.
     void solve() {
         const size_t n_nodes = n2.size() / 16;
         dp.resize(n_nodes);
-        for (size_t jj = n_nodes; jj-- > 0;) {  // children have larger indices than their parent
+        const int threads = host_threads();
+        struct Range {
+            size_t lo, hi;
+        };
+        std::vector<Range> subtrees;
+        std::vector<size_t> top;
+        const size_t grain = std::max<size_t>(n_nodes / (size_t)(8 * threads), 4096);
+        std::vector<Range> todo{Range{0, n_nodes}};
+        while (!todo.empty()) {
+            const Range r = todo.back();
+            todo.pop_back();
+            if (r.hi - r.lo <= grain || threads == 1) {
+                subtrees.push_back(r);
+                continue;
+            }
+            top.push_back(r.lo);
+            const int32_t r0 = child_ref((int32_t)r.lo, 0), r1 = child_ref((int32_t)r.lo, 1);
+            if (r0 >= 0 && r1 >= 0) {
+                todo.push_back(Range{(size_t)r0, (size_t)r1});
+                todo.push_back(Range{(size_t)r1, r.hi});
+            } else if (r0 >= 0) {
+                todo.push_back(Range{(size_t)r0, r.hi});
+            } else if (r1 >= 0) {
+                todo.push_back(Range{(size_t)r1, r.hi});
+            }
+        }
+        parallel_for(subtrees.size(), threads, 1, [&](size_t i) {
+            for (size_t jj = subtrees[i].hi; jj-- > subtrees[i].lo;) solve_node(jj);
+        });
+        std::sort(top.begin(), top.end());
+        for (size_t i = top.size(); i-- > 0;) solve_node(top[i]);
+    }
+
+    void solve_node(size_t jj) {
+        {
             const int32_t j = (int32_t)jj;
             Dp& d = dp[jj];
             float cb[2][6], carea[2];
@@ -335,9 +496,23 @@ struct Cw8Builder {
         int32_t node2;
         uint32_t index, level;
     };
-
-    void emit(const Pending& pd, std::vector<Pending>& queue) {
+    // One 8-wide node being formed: its children, their slots, and where its inner children and leaf
+    // triangles go.  Nodes are emitted level by level: plan() (children + slots, independent per node) in
+    // parallel, a prefix sum over the level in index order for child_base / tri_base, write() in
+    // parallel.  The layout is the breadth-first one a sequential queue produces, whatever the thread count.
+    struct Work {
+        Pending pd;
         Child ch[8];
+        int k;
+        int child_in[8];  // slot -> child, -1 = empty
+        float lo[3], hi[3];
+        uint32_t n_inner, n_tris;
+        uint32_t child_base, tri_base;
+    };
+
+    void plan(const Pending& pd, Work& w) const {
+        w.pd = pd;
+        Child* ch = w.ch;
         int k = 0;
         if (dp[pd.node2].is_leaf && pd.level == 0) {  // whole mesh fits one leaf: root node with a single leaf child
             const Dp& d = dp[pd.node2];
@@ -347,9 +522,9 @@ struct Cw8Builder {
         } else {
             distribute(pd.node2, 8, ch, k);
         }
-        depth = std::max(depth, pd.level + 1);
-
-        float lo[3], hi[3];
+        w.k = k;
+        float* lo = w.lo;
+        float* hi = w.hi;
         for (int a = 0; a < 3; a++) {
             lo[a] = ch[0].box[a];
             hi[a] = ch[0].box[3 + a];
@@ -360,8 +535,19 @@ struct Cw8Builder {
         }
         // slot assignment: slot bits (x,y,z) = which side of the node centre the child sits on, so that
         // slot ^ (7 - ray octant) orders children front to back; greedy on dot(child centre - node centre, slot dir)
-        int slot_of[8], child_in[8];
+        int slot_of[8];
+        int* child_in = w.child_in;
         for (int i = 0; i < 8; i++) slot_of[i] = child_in[i] = -1;
+        float score[8][8];
+        for (int i = 0; i < k; i++) {
+            float off[3];
+            for (int a = 0; a < 3; a++) off[a] = 0.5f * (ch[i].box[a] + ch[i].box[3 + a]) - 0.5f * (lo[a] + hi[a]);
+            for (int s = 0; s < 8; s++) {
+                float c = 0.0f;
+                for (int a = 0; a < 3; a++) c += ((s >> (2 - a)) & 1) ? off[a] : -off[a];
+                score[i][s] = c;
+            }
+        }
         for (int round = 0; round < k; round++) {
             float best = -std::numeric_limits<float>::infinity();
             int bi = -1, bs = -1;
@@ -369,13 +555,8 @@ struct Cw8Builder {
                 if (slot_of[i] >= 0) continue;
                 for (int s = 0; s < 8; s++) {
                     if (child_in[s] >= 0) continue;
-                    float c = 0.0f;
-                    for (int a = 0; a < 3; a++) {
-                        const float off = 0.5f * (ch[i].box[a] + ch[i].box[3 + a]) - 0.5f * (lo[a] + hi[a]);
-                        c += ((s >> (2 - a)) & 1) ? off : -off;
-                    }
-                    if (c > best) {
-                        best = c;
+                    if (score[i][s] > best) {
+                        best = score[i][s];
                         bi = i;
                         bs = s;
                     }
@@ -384,7 +565,21 @@ struct Cw8Builder {
             slot_of[bi] = bs;
             child_in[bs] = bi;
         }
+        w.n_inner = w.n_tris = 0;
+        for (int s = 0; s < 8; s++) {
+            const int i = child_in[s];
+            if (i < 0) continue;
+            if (ch[i].ref >= 0) w.n_inner++;
+            else w.n_tris += (~(uint32_t)ch[i].ref & 3u) + 1u;
+        }
+    }
 
+    // node words, leaf triangle order and the next level's entries of one planned node (storage is sized by the caller)
+    void write(const Work& wk, Pending* next_level, uint32_t next_level_base) {
+        const Child* ch = wk.ch;
+        const int* child_in = wk.child_in;
+        const float* lo = wk.lo;
+        const float* hi = wk.hi;
         // quantisation frame: p = lo, per-axis power-of-two scale with 255 * scale >= extent
         uint32_t e_byte[3];
         double scale[3];
@@ -396,38 +591,30 @@ struct Cw8Builder {
             e_byte[a] = (uint32_t)(e + 127);
             scale[a] = std::ldexp(1.0, e);
         }
-
-        uint32_t* w = &nodes[(size_t)pd.index * 20];
+        uint32_t* w = &nodes[(size_t)wk.pd.index * 20];
         std::memcpy(w, lo, 12);
-        uint32_t imask = 0, n_inner = 0;
+        uint32_t imask = 0;
         for (int s = 0; s < 8; s++)
-            if (child_in[s] >= 0 && ch[child_in[s]].ref >= 0) {
-                imask |= 1u << s;
-                n_inner++;
-            }
+            if (child_in[s] >= 0 && ch[child_in[s]].ref >= 0) imask |= 1u << s;
         w[3] = e_byte[0] | (e_byte[1] << 8) | (e_byte[2] << 16) | (imask << 24);
-        const uint32_t child_base = (uint32_t)(nodes.size() / 20);
-        const uint32_t tri_base = (uint32_t)order8.size();
-        w[4] = child_base;
-        w[5] = tri_base;
-        nodes.resize(nodes.size() + (size_t)n_inner * 20);
-        w = &nodes[(size_t)pd.index * 20];  // resize may have moved the storage
+        w[4] = wk.child_base;
+        w[5] = wk.tri_base;
         uint8_t meta[8] = {}, q[6][8];
         for (int a = 0; a < 6; a++)
             for (int s = 0; s < 8; s++) q[a][s] = a < 3 ? 255 : 0;  // empty slot: inverted box, meta 0
-        uint32_t rank = 0;
+        uint32_t rank = 0, off = 0;
         for (int s = 0; s < 8; s++) {
             const int i = child_in[s];
             if (i < 0) continue;
             if (ch[i].ref >= 0) {
                 meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
-                queue.push_back(Pending{ch[i].ref, child_base + rank, pd.level + 1});
+                next_level[wk.child_base + rank - next_level_base] = Pending{ch[i].ref, wk.child_base + rank, wk.pd.level + 1};
                 rank++;
             } else {
                 const uint32_t ref = ~(uint32_t)ch[i].ref, first = ref >> 2, cnt = (ref & 3u) + 1u;  // cnt <= 3
-                const uint32_t off = (uint32_t)order8.size() - tri_base;
                 meta[s] = (uint8_t)((((1u << cnt) - 1u) << 5) | off);
-                for (uint32_t t = 0; t < cnt; t++) order8.push_back(order2[first + t]);
+                for (uint32_t t = 0; t < cnt; t++) order8[(size_t)wk.tri_base + off + t] = order2[first + t];
+                off += cnt;
             }
             for (int a = 0; a < 3; a++) {
                 double ql = std::floor(((double)ch[i].box[a] - (double)lo[a]) / scale[a]);
@@ -443,13 +630,33 @@ struct Cw8Builder {
     }
 
     void build() {
+        RT_BVH_T(t0);
         solve();
-        nodes.assign(20, 0u);
-        std::vector<Pending> queue;
-        queue.push_back(Pending{0, 0, 0});
-        for (size_t head = 0; head < queue.size(); head++) {
-            const Pending pd = queue[head];
-            emit(pd, queue);
+        RT_BVH_T(t1);
+        RT_BVH_REPORT("  collapse: DP", t0, t1);
+        const int threads = host_threads();
+        nodes.clear();
+        order8.clear();
+        std::vector<Pending> level{Pending{0, 0, 0}}, next;
+        std::vector<Work> work;
+        uint32_t node_count = 1, tri_count = 0;
+        depth = 0;
+        while (!level.empty()) {
+            depth = level[0].level + 1;
+            work.resize(level.size());
+            parallel_for(level.size(), threads, 256, [&](size_t i) { plan(level[i], work[i]); });
+            const uint32_t next_base = node_count;
+            for (Work& w : work) {  // index order = the order a sequential breadth-first queue visits them
+                w.child_base = node_count;
+                w.tri_base = tri_count;
+                node_count += w.n_inner;
+                tri_count += w.n_tris;
+            }
+            nodes.resize((size_t)node_count * 20, 0u);
+            order8.resize(tri_count);
+            next.resize(node_count - next_base);
+            parallel_for(work.size(), threads, 256, [&](size_t i) { write(work[i], next.data(), next_base); });
+            level.swap(next);
         }
     }
 };
@@ -458,6 +665,7 @@ struct Cw8Builder {
 
 bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, uint32_t max_depth, BvhResult* out) {
     if (!v0 || !e1 || !e2 || n == 0 || n >= (1u << 29) || !out) return false;
+    RT_BVH_T(t_start);
     std::vector<Box> tri_box(n);
     std::vector<float> centroid(3 * (size_t)n);
     float maxabs = 0.0f;
@@ -480,11 +688,12 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
     out->order.resize(n);
     for (uint32_t i = 0; i < n; i++) out->order[i] = i;
     std::vector<float> binary;
-    binary.reserve(16 * (size_t)(n / 2 + 16));
     // conservative padding: absorbs the rounding of the slab test and of Moeller-Trumbore's t
     out->pad = 2e-5f * std::max(maxabs, 1.0f);
     const uint32_t leaf_max = 1;  // the binary tree goes down to single triangles; the collapse forms the <= 3-triangle leaves
-    Builder b{tri_box, centroid, out->order, binary, out->pad, max_depth, leaf_max};
+    std::atomic<int> spare_threads{host_threads() - 1};
+    Builder b{tri_box, centroid, out->order, binary, out->pad, max_depth, leaf_max, &spare_threads, host_threads()};
+    out->sah_area = 0.0;
     if (n <= leaf_max) {
         // one node whose two slots name the same leaf (testing it twice is idempotent)
         binary.resize(16);
@@ -500,16 +709,24 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
         nd[14] = nd[15] = 0.0f;
         out->depth = 1;
     } else {
-        b.build(0, n, 0);
-        out->depth = b.depth_reached + 1;
+        RT_BVH_T(t_prep);
+        RT_BVH_REPORT("prepare", t_start, t_prep);
+        binary.resize(16 * (size_t)(n - 1));  // single-triangle leaves: exactly n - 1 inner nodes
+        const Builder::Sub top = b.build(0, n, 0, 0);
+        out->depth = top.depth_reached + 1;
+        out->sah_area = top.sah;
+        RT_BVH_T(t_bin);
+        RT_BVH_REPORT("binary SAH build", t_prep, t_bin);
     }
-    out->sah_area = b.sah;
     // collapse to compressed 8-wide nodes; triangles are re-ordered so every node's leaf triangles are contiguous
     std::vector<uint32_t> order2;
     order2.swap(out->order);
     out->order.reserve(n);
     Cw8Builder cw{binary, order2, out->nodes, out->order, 0, out->cost_prim, {}};
+    RT_BVH_T(t_c0);
     cw.build();
+    RT_BVH_T(t_c1);
+    RT_BVH_REPORT("collapse + emit", t_c0, t_c1);
     if (out->order.size() != n) return false;
     out->n_nodes = (uint32_t)(out->nodes.size() / 20);
     out->depth = cw.depth;

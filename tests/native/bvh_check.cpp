@@ -92,6 +92,9 @@ int main(int argc, char** argv) {
         if (reached[t] != 1) { std::printf("FAIL triangle %u reached %u times\n", t, reached[t]); return 1; }
     if (n_visited != b.n_nodes) { std::puts("FAIL unreachable nodes"); return 1; }
     if (max_level != b.depth || b.stack_need != b.depth + 1) { std::printf("FAIL depth %u vs %u\n", max_level, b.depth); return 1; }
-    std::printf("OK n=%u nodes=%u depth=%u tris/node=%.2f\n", n, b.n_nodes, b.depth, (double)n / b.n_nodes);
+    unsigned long long h = 1469598103934665603ull;  // FNV-1a over the node words and the leaf order: the builder's whole output
+    for (uint32_t w : b.nodes) h = (h ^ w) * 1099511628211ull;
+    for (uint32_t w : b.order) h = (h ^ w) * 1099511628211ull;
+    std::printf("OK n=%u nodes=%u depth=%u tris/node=%.2f hash=%016llx\n", n, b.n_nodes, b.depth, (double)n / b.n_nodes, h);
     return 0;
 }

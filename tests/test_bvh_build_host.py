@@ -1,6 +1,7 @@
 """CPU test of the native host code on the hot path's input side: the compressed 8-wide BVH builder
 (csrc/bvh_build.cpp) compiled with AddressSanitizer + UBSan and checked structurally
-(tests/native/bvh_check.cpp).  No GPU."""
+(tests/native/bvh_check.cpp); its threads under ThreadSanitizer, and its output must not depend on the
+number of threads.  No GPU."""
 import os
 import subprocess
 
@@ -12,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def checker(tmp_path_factory):
     exe = tmp_path_factory.mktemp("bvh") / "bvh_check"
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                     os.path.join(ROOT, "tests", "native", "bvh_check.cpp"), os.path.join(ROOT, "raytracing_engine_amd", "csrc", "bvh_build.cpp"),
                     "-o", str(exe)], check=True)
     return str(exe)
@@ -22,3 +23,22 @@ def checker(tmp_path_factory):
 def test_bvh_structure_under_sanitizers(checker, n, seed, edge):
     out = subprocess.run([checker, str(n), str(seed), str(edge)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+@pytest.fixture(scope="module")
+def checker_tsan(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("bvh_tsan") / "bvh_check"
+    subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-pthread", "-fsanitize=thread",
+                    os.path.join(ROOT, "tests", "native", "bvh_check.cpp"), os.path.join(ROOT, "raytracing_engine_amd", "csrc", "bvh_build.cpp"),
+                    "-o", str(exe)], check=True)
+    return str(exe)
+
+
+def test_builder_threads_are_race_free_and_deterministic(checker_tsan):
+    """150 000 triangles: subtree threads, the chunked binning of big nodes, the per-subtree dynamic program
+    and the level-parallel node emission all run; ThreadSanitizer must stay silent and one thread must
+    produce the very same nodes and leaf order as all of them."""
+    many = subprocess.run([checker_tsan, "150000", "11", "0.2"], capture_output=True, text=True)
+    assert many.returncode == 0 and many.stdout.startswith("OK") and "ThreadSanitizer" not in many.stderr, many.stdout + many.stderr
+    one = subprocess.run(["taskset", "-c", "0", checker_tsan, "150000", "11", "0.2"], capture_output=True, text=True)
+    assert one.returncode == 0 and one.stdout == many.stdout, one.stdout + one.stderr
