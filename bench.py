@@ -33,6 +33,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # run under rocprofv3 by measure_traffic()
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child runs (roofline.traffic = null)")
+    ap.add_argument("--exchange", choices=["pipelined", "serial"], default="pipelined",
+                    help="N > 1: gather + de-tile of frame k beside the render of frame k+1 (second stream, "
+                         "double-buffered tiles), or strictly after it")
+    ap.add_argument("--exercise-exchange", action="store_true",
+                    help="run the N > 1 code path (streams, events, gather, de-tile) with a 1-rank communicator: a test of "
+                         "the plumbing on one GPU, not a measurement")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="debug only: all ranks share cuda:0 and gather through host memory over gloo (exercises the N>1 "
                          "control flow on a 1-GPU box; the line it prints is marked rehearsal and is not a measurement)")
@@ -316,8 +322,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.exercise_exchange
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.rehearse_one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -337,33 +345,67 @@ def main():
     tiles_per_rank = -(-(tx * ty) // world)
     T = 64
     frame = torch.empty((wl.height, wl.width, 3), dtype=torch.float32, device=dev)
-    if world > 1:
-        mine = torch.zeros((tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev)
-        gathered = torch.empty((world, tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev) if rank == 0 else None
-        # One explicit (non-null) stream carries render -> RCCL gather -> de-tile in order.  The null
+    pipelined = multi and args.exchange == "pipelined" and not args.rehearse_one_gpu
+    if multi:
+        n_buf = 2 if pipelined else 1
+        mine = [torch.zeros((tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev) for _ in range(n_buf)]
+        gathered = [torch.empty((world, tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev) if rank == 0 else None for _ in range(n_buf)]
+        # One explicit (non-null) stream carries the renders (and the de-tile kernels) in order.  The null
         # stream must not be used here: rt_set_stream(NULL) selects the context's own non-blocking
         # stream, which does not synchronise with torch's default stream.
         side = torch.cuda.Stream(device=dev)
         r.set_stream(side.cuda_stream)
+        # The exchange of frame k runs on a second stream beside the render of frame k+1 (tiles and
+        # gather buffers double-buffered): side: render(k) | comm: gather(k) || side: render(k+1),
+        # wait gather(k), de-tile(k).  xGMI transfers and the de-tile of a frame then cost no render time.
+        comm = torch.cuda.Stream(device=dev) if pipelined else side
+        ev_rendered = [torch.cuda.Event() for _ in range(n_buf)]
+        ev_gathered = [torch.cuda.Event() for _ in range(n_buf)]
+    state = {"i": 0, "pending": None}
+
+    def finish(k):
+        """Behind the newest render on `side`: wait for exchange k, scatter its tiles into the frame."""
+        with torch.cuda.stream(side):
+            side.wait_event(ev_gathered[k])
+            if rank == 0:
+                r.detile_device(gathered[k].data_ptr(), world, tiles_per_rank, frame.data_ptr())
 
     def step():
-        if world == 1:
+        if not multi:
             wl.step(frame.data_ptr(), False)
-        else:
+            return
+        k = state["i"] % len(mine)
+        state["i"] += 1
+        with torch.cuda.stream(side):
+            wl.step(mine[k].data_ptr(), True)  # enqueued on `side` by the context
+            ev_rendered[k].record(side)
+        if args.rehearse_one_gpu:  # gloo gathers host tensors
+            side.synchronize()
+            host_all = torch.empty(gathered[k].shape) if rank == 0 else None
+            R.host.gather_tiles(mine[k].cpu(), host_all, rank, dist)
             with torch.cuda.stream(side):
-                wl.step(mine.data_ptr(), True)                   # enqueued on `side` by the context
-                if args.rehearse_one_gpu:  # gloo gathers host tensors
-                    side.synchronize()
-                    host_all = torch.empty(gathered.shape) if rank == 0 else None
-                    R.host.gather_tiles(mine.cpu(), host_all, rank, dist)
-                    if rank == 0:
-                        gathered.copy_(host_all)
-                else:
-                    R.host.gather_tiles(mine, gathered, rank, dist)  # RCCL waits for / is waited on by `side`
                 if rank == 0:
-                    r.detile_device(gathered.data_ptr(), world, tiles_per_rank, frame.data_ptr())
+                    gathered[k].copy_(host_all)
+                    r.detile_device(gathered[k].data_ptr(), world, tiles_per_rank, frame.data_ptr())
+            return
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev_rendered[k])
+            R.host.gather_tiles(mine[k], gathered[k], rank, dist)  # RCCL waits for / is waited on by `comm`
+            ev_gathered[k].record(comm)
+        if pipelined:
+            if state["pending"] is not None:
+                finish(state["pending"])
+            state["pending"] = k
+        else:
+            finish(k)
+
+    def drain():
+        if multi and state["pending"] is not None:
+            finish(state["pending"])
+            state["pending"] = None
 
     def fence():
+        drain()
         r.synchronize()
         torch.cuda.synchronize()
         if world > 1:
@@ -394,20 +436,24 @@ def main():
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
                "config": dict(wl.describe(), parallelism=f"tile-split x{world}" if world > 1 else "single GPU",
                               rays_per_step=int(rays))}
+        check_split = (args.rehearse_one_gpu and world > 1) or args.exercise_exchange
         if args.rehearse_one_gpu:
             out["rehearsal"] = "all ranks on one GPU, gloo gather through host memory: NOT a measurement"
+        if args.exercise_exchange:
+            out["rehearsal"] = "the N > 1 code path with a 1-rank communicator: NOT a measurement"
+        if check_split:
             # the de-tiled frame of the split render must equal a single-context render of the same frame
             import numpy as np
             split = frame.cpu().numpy().copy()
-        if world > 1:
+        if multi:
             torch.cuda.synchronize()
             r.set_stream(None)
         r.set_partition(0, 1)
-        if args.rehearse_one_gpu and world > 1:
+        if check_split:
             wl.step(frame.data_ptr(), False)
             r.synchronize()
             out["rehearsal_split_equals_single"] = bool((frame.cpu().numpy() == split).all())
-        if world == 1:
+        if not multi:
             out["roofline"] = wl.roofline()
             if not args.no_traffic:
                 tr = measure_traffic(args.workload, wl.dominant_kernel)
@@ -417,7 +463,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     r.close()
