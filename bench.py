@@ -33,9 +33,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # run under rocprofv3 by measure_traffic()
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child runs (roofline.traffic = null)")
-    ap.add_argument("--exchange", choices=["pipelined", "serial"], default="pipelined",
-                    help="N > 1: gather + de-tile of frame k beside the render of frame k+1 (second stream, "
-                         "double-buffered tiles), or strictly after it")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="frame lanes: consecutive steps go round-robin to this many independent contexts (own stream, own "
+                         "pyramid / wavefront state, own output and exchange buffers), so the latency-bound parts of a frame - "
+                         "coarse pyramid levels, the tails of the persistent traversal kernels, the RCCL gather - overlap with "
+                         "the next frames; 1 = strictly one frame after the other")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="run the N > 1 code path (streams, events, gather, de-tile) with a 1-rank communicator: a test of "
                          "the plumbing on one GPU, not a measurement")
@@ -344,69 +346,71 @@ def main():
     tx, ty, owned = r.tile_info()
     tiles_per_rank = -(-(tx * ty) // world)
     T = 64
-    frame = torch.empty((wl.height, wl.width, 3), dtype=torch.float32, device=dev)
-    pipelined = multi and args.exchange == "pipelined" and not args.rehearse_one_gpu
-    if multi:
-        n_buf = 2 if pipelined else 1
-        mine = [torch.zeros((tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev) for _ in range(n_buf)]
-        gathered = [torch.empty((world, tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev) if rank == 0 else None for _ in range(n_buf)]
-        # One explicit (non-null) stream carries the renders (and the de-tile kernels) in order.  The null
-        # stream must not be used here: rt_set_stream(NULL) selects the context's own non-blocking
-        # stream, which does not synchronise with torch's default stream.
-        side = torch.cuda.Stream(device=dev)
-        r.set_stream(side.cuda_stream)
-        # The exchange of frame k runs on a second stream beside the render of frame k+1 (tiles and
-        # gather buffers double-buffered): side: render(k) | comm: gather(k) || side: render(k+1),
-        # wait gather(k), de-tile(k).  xGMI transfers and the de-tile of a frame then cost no render time.
-        comm = torch.cuda.Stream(device=dev) if pipelined else side
-        ev_rendered = [torch.cuda.Event() for _ in range(n_buf)]
-        ev_gathered = [torch.cuda.Event() for _ in range(n_buf)]
-    state = {"i": 0, "pending": None}
 
-    def finish(k):
-        """Behind the newest render on `side`: wait for exchange k, scatter its tiles into the frame."""
-        with torch.cuda.stream(side):
-            side.wait_event(ev_gathered[k])
-            if rank == 0:
-                r.detile_device(gathered[k].data_ptr(), world, tiles_per_rank, frame.data_ptr())
+    # Frame lanes: lane 0 is (r, wl); the others are further contexts with the same scene.  Step i runs on
+    # lane i % L.  Inside a lane everything is stream-ordered: render -> [RCCL gather -> de-tile]; lanes only
+    # share the GPU (and the communicator, whose gathers are issued in step order on every rank).
+    n_lanes = 1 if args.rehearse_one_gpu else max(1, min(args.frames_in_flight, 8))
+
+    class Lane:
+        pass
+
+    lanes = []
+    for li in range(n_lanes):
+        ln = Lane()
+        ln.r = r if li == 0 else R.Renderer(local_rank)
+        ln.wl = wl if li == 0 else WORKLOADS[args.workload](R, ln.r)
+        ln.r.set_partition(rank, world)
+        ln.frame = torch.empty((wl.height, wl.width, 3), dtype=torch.float32, device=dev)
+        if multi:
+            ln.mine = torch.zeros((tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev)
+            ln.gathered = torch.empty((world, tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+            # An explicit (non-null) stream per lane carries render and de-tile in order.  The null stream must
+            # not be used here: rt_set_stream(NULL) selects the context's own non-blocking stream, which does
+            # not synchronise with torch's default stream.
+            ln.stream = torch.cuda.Stream(device=dev)
+            ln.r.set_stream(ln.stream.cuda_stream)
+            ln.ev_rendered = torch.cuda.Event()
+            ln.ev_gathered = torch.cuda.Event()
+        lanes.append(ln)
+    frame = lanes[0].frame
+    comm = torch.cuda.Stream(device=dev) if multi else None  # every gather, in step order
+    state = {"i": 0}
 
     def step():
-        if not multi:
-            wl.step(frame.data_ptr(), False)
-            return
-        k = state["i"] % len(mine)
+        ln = lanes[state["i"] % n_lanes]
         state["i"] += 1
-        with torch.cuda.stream(side):
-            wl.step(mine[k].data_ptr(), True)  # enqueued on `side` by the context
-            ev_rendered[k].record(side)
+        if not multi:
+            ln.wl.step(ln.frame.data_ptr(), False)
+            return
+        with torch.cuda.stream(ln.stream):
+            ln.wl.step(ln.mine.data_ptr(), True)  # enqueued on the lane's stream by the context
+            ln.ev_rendered.record(ln.stream)
         if args.rehearse_one_gpu:  # gloo gathers host tensors
-            side.synchronize()
-            host_all = torch.empty(gathered[k].shape) if rank == 0 else None
-            R.host.gather_tiles(mine[k].cpu(), host_all, rank, dist)
-            with torch.cuda.stream(side):
+            ln.stream.synchronize()
+            host_all = torch.empty(ln.gathered.shape) if rank == 0 else None
+            R.host.gather_tiles(ln.mine.cpu(), host_all, rank, dist)
+            with torch.cuda.stream(ln.stream):
                 if rank == 0:
-                    gathered[k].copy_(host_all)
-                    r.detile_device(gathered[k].data_ptr(), world, tiles_per_rank, frame.data_ptr())
+                    ln.gathered.copy_(host_all)
+                    ln.r.detile_device(ln.gathered.data_ptr(), world, tiles_per_rank, ln.frame.data_ptr())
             return
         with torch.cuda.stream(comm):
-            comm.wait_event(ev_rendered[k])
-            R.host.gather_tiles(mine[k], gathered[k], rank, dist)  # RCCL waits for / is waited on by `comm`
-            ev_gathered[k].record(comm)
-        if pipelined:
-            if state["pending"] is not None:
-                finish(state["pending"])
-            state["pending"] = k
-        else:
-            finish(k)
+            comm.wait_event(ln.ev_rendered)
+            R.host.gather_tiles(ln.mine, ln.gathered, rank, dist)  # RCCL waits for / is waited on by `comm`
+            ln.ev_gathered.record(comm)
+        with torch.cuda.stream(ln.stream):
+            # the lane's next render reuses `mine` / `gathered`: it is ordered behind this wait
+            ln.stream.wait_event(ln.ev_gathered)
+            if rank == 0:
+                ln.r.detile_device(ln.gathered.data_ptr(), world, tiles_per_rank, ln.frame.data_ptr())
 
     def drain():
-        if multi and state["pending"] is not None:
-            finish(state["pending"])
-            state["pending"] = None
+        for ln in lanes:
+            ln.r.synchronize()
 
     def fence():
         drain()
-        r.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -435,7 +439,7 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
                "config": dict(wl.describe(), parallelism=f"tile-split x{world}" if world > 1 else "single GPU",
-                              rays_per_step=int(rays))}
+                              rays_per_step=int(rays), frames_in_flight=n_lanes)}
         check_split = (args.rehearse_one_gpu and world > 1) or args.exercise_exchange
         if args.rehearse_one_gpu:
             out["rehearsal"] = "all ranks on one GPU, gloo gather through host memory: NOT a measurement"
@@ -444,15 +448,18 @@ def main():
         if check_split:
             # the de-tiled frame of the split render must equal a single-context render of the same frame
             import numpy as np
-            split = frame.cpu().numpy().copy()
+            split = [ln.frame.cpu().numpy().copy() for ln in lanes[:max(1, min(n_lanes, args.steps + args.warmup))]]
         if multi:
             torch.cuda.synchronize()
             r.set_stream(None)
+        for ln in lanes[1:]:  # lane 0 goes on to the roofline / CPU-baseline legs
+            ln.r.close()
         r.set_partition(0, 1)
         if check_split:
             wl.step(frame.data_ptr(), False)
             r.synchronize()
-            out["rehearsal_split_equals_single"] = bool((frame.cpu().numpy() == split).all())
+            single = frame.cpu().numpy()
+            out["rehearsal_split_equals_single"] = bool(all((single == f).all() for f in split))
         if not multi:
             out["roofline"] = wl.roofline()
             if not args.no_traffic:
@@ -463,6 +470,9 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
+    if rank != 0:
+        for ln in lanes[1:]:
+            ln.r.close()
     if multi:
         dist.barrier()
         dist.destroy_process_group()

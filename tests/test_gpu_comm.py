@@ -38,21 +38,21 @@ def test_single_rank_gather_and_detile():
         r.close()
 
 
-@pytest.mark.parametrize("exchange", ["pipelined", "serial"])
-def test_bench_exchange_path_with_one_rank(exchange):
-    """bench.py's N > 1 path (two streams, events, torch.distributed gather over RCCL, de-tile; frame k's
-    exchange beside frame k+1's render) driven with a 1-rank communicator: the de-tiled frame must be the
-    single-context frame."""
+@pytest.mark.parametrize("lanes", [3, 1])
+def test_bench_exchange_path_with_one_rank(lanes):
+    """bench.py's N > 1 path (one stream per frame lane, events, torch.distributed gather over RCCL on the
+    exchange stream, de-tile; consecutive frames on different lanes overlap) driven with a 1-rank
+    communicator: every lane's de-tiled frame must be the single-context frame."""
     import json
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541" if exchange == "pipelined" else "29542")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--exercise-exchange", "--exchange", exchange, "--steps", "3", "--warmup", "2",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29540 + lanes))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--exercise-exchange", "--frames-in-flight", str(lanes), "--steps", "4", "--warmup", "2",
                           "--workload", "spheres8_1080p_4spp", "--no-traffic", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["rehearsal_split_equals_single"] is True
-    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["frames_in_flight"] == lanes
