@@ -185,8 +185,10 @@ int rt_get_stats(const rt_ctx* ctx, rt_stats* stats);
  * frame and presented) with "present" = the pixels arriving in host memory.  A slot is one swapchain
  * image: a device frame, a pinned host frame and two events.  rt_frame_submit waits until the slot's
  * previous frame has reached the host (the image fence, :882-884), enqueues the render on the
- * context's stream and the read-back on a copy stream behind it, and returns without waiting; the
- * read-back of frame k overlaps the render of frame k+1.  rt_frame_wait blocks until the slot's
+ * slot's own render lane (a child context: own stream and buffers, configuration / scene / mesh of
+ * this context as of the submit) and the read-back on a copy stream behind it, and returns without
+ * waiting: frames in different slots overlap on the GPU, and every read-back overlaps later renders.
+ * Frames of one slot complete in submit order; different slots are independent.  rt_frame_wait blocks until the slot's
  * pixels are in host memory and returns a pointer that stays valid until the slot is submitted
  * again.  format RT_FRAME_F32 = width*height*3 f32 (linear RGB), RT_FRAME_RGBA8 = width*height*4
  * bytes as rt_read_rgba8 defines them.  rt_resize releases the slots: configure again afterwards.

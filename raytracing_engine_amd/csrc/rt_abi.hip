@@ -343,7 +343,6 @@ int rt_create(rt_ctx** out, int device_ordinal) {
     rt_default_config(&c->cfg);
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 1024 * sizeof(uint64_t));
@@ -399,6 +398,7 @@ int rt_set_config(rt_ctx* ctx, const rt_config* cfg) {
         if (!(r >= 0.0f) || !(r < 3.0e38f)) return c->fail(RT_ERR_INVALID, "repeat periods must be finite and >= 0");
     if (variant && cfg->fuse_levels) return c->fail(RT_ERR_INVALID, "march_algorithm / repeat need fuse_levels = 0");
     c->cfg = *cfg;
+    c->state_version++;
     return RT_OK;
 }
 
@@ -414,6 +414,7 @@ int rt_set_scene(rt_ctx* ctx, const void* mutable_data, size_t bytes) {
     if (s.matCount > RT_MAX_MATERIALS) return c->fail(RT_ERR_INVALID, "matCount %u > %u", s.matCount, RT_MAX_MATERIALS);
     c->scene = s;
     c->have_scene = true;
+    c->state_version++;
     return RT_OK;
 }
 

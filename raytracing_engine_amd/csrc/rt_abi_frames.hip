@@ -4,9 +4,13 @@
 // (wait the acquired image's fence, record, submit behind the previous frame's future, present,
 // keep the new fence).  Here a "swapchain image" is a slot = device frame + pinned host frame + two
 // events, "present" is the pixels arriving in host memory, and the GPU-side ordering is two HIP
-// streams: renders run back to back on the context's stream (they share the pyramid / wavefront
-// buffers, like the reference's single queue), each read-back runs on a copy stream behind the
-// render it belongs to, so the copy of frame k overlaps the render of frame k+1.
+// streams.  Every slot is also a render LANE: a child context of its own (own stream, own pyramid /
+// wavefront buffers; configuration and scene copied from the parent, the triangle mesh borrowed from
+// it), so the frames in different slots overlap on the GPU as well - the coarse pyramid levels of
+// path A and the tails of path B's traversal kernels are latency-bound and leave most of the chip
+// idle for one frame alone.  Each read-back runs on the copy stream behind the render it belongs to.
+// (The reference chains its frames on one queue, src/main.rs:909-915; overlapping them is this
+// build's addition and does not change any frame.)
 #include <vector>
 
 #include "rt_internal.h"
@@ -16,6 +20,8 @@ using rt::Ctx;
 namespace {
 
 struct Slot {
+    rt_ctx* lane = nullptr;     // child context that renders this slot's frames
+    uint64_t lane_version = 0;  // parent state_version the lane was last synchronised with
     float* d_rgb = nullptr;     // render target (f32 x 3)
     uint8_t* d_rgba = nullptr;  // RT_FRAME_RGBA8 only
     void* h_pixels = nullptr;   // pinned
@@ -36,6 +42,7 @@ void release(Frames* f) {
     if (!f) return;
     if (f->copy_stream) (void)hipStreamSynchronize(f->copy_stream);
     for (Slot& s : f->slots) {
+        if (s.lane) rt_destroy(s.lane);  // synchronises the lane's streams first
         if (s.d_rgb) (void)hipFree(s.d_rgb);
         if (s.d_rgba) (void)hipFree(s.d_rgba);
         if (s.h_pixels) (void)hipHostFree(s.h_pixels);
@@ -46,8 +53,22 @@ void release(Frames* f) {
     delete f;
 }
 
+// Bring a slot's lane up to date with the parent's configuration, scene and mesh.
+int sync_lane(Ctx* c, Slot& s) {
+    if (s.lane_version == c->state_version) return RT_OK;
+    Ctx* l = reinterpret_cast<Ctx*>(s.lane);
+    RT_HIP(c, hipStreamSynchronize(l->stream));
+    if (l->aux_stream) RT_HIP(c, hipStreamSynchronize(l->aux_stream));
+    l->cfg = c->cfg;
+    l->scene = c->scene;
+    l->have_scene = c->have_scene;
+    rt::pt_borrow_mesh(l, c);
+    s.lane_version = c->state_version;
+    return RT_OK;
+}
+
 // Common part of the two submit entry points: checks, the slot's fence, then `render` enqueues the
-// frame into the slot's device buffer on the context's stream.
+// frame into the slot's device buffer on the slot's lane.
 template <typename Render>
 int submit(Ctx* c, uint32_t slot, Render render) {
     Frames* f = static_cast<Frames*>(c->frames);
@@ -60,13 +81,15 @@ int submit(Ctx* c, uint32_t slot, Render render) {
         RT_HIP(c, hipEventSynchronize(s.ev_ready));
         s.pending = false;
     }
-    if (int rc = render(s.d_rgb)) return rc;
+    if (int rc = sync_lane(c, s)) return rc;
+    Ctx* l = reinterpret_cast<Ctx*>(s.lane);
+    if (int rc = render(s.lane, s.d_rgb)) return c->fail(rc, "%s", rt_last_error(s.lane));
     const void* src = s.d_rgb;
     if (f->format == RT_FRAME_RGBA8) {
-        if (int rc = rt::launch_to_rgba8(c, s.d_rgb, s.d_rgba, (uint64_t)f->width * f->height)) return rc;
+        if (int rc = rt::launch_to_rgba8(l, s.d_rgb, s.d_rgba, (uint64_t)f->width * f->height)) return c->fail(rc, "%s", rt_last_error(s.lane));
         src = s.d_rgba;
     }
-    RT_HIP(c, hipEventRecord(s.ev_rendered, c->stream));
+    RT_HIP(c, hipEventRecord(s.ev_rendered, l->stream));
     RT_HIP(c, hipStreamWaitEvent(f->copy_stream, s.ev_rendered, 0));
     RT_HIP(c, hipMemcpyAsync(s.h_pixels, src, f->bytes, hipMemcpyDeviceToHost, f->copy_stream));
     RT_HIP(c, hipEventRecord(s.ev_ready, f->copy_stream));
@@ -81,6 +104,19 @@ namespace rt {
 void frames_free(Ctx* c) {
     release(static_cast<Frames*>(c->frames));
     c->frames = nullptr;
+}
+
+void frames_drop_mesh(Ctx* c) {
+    Frames* f = static_cast<Frames*>(c->frames);
+    if (!f) return;
+    for (Slot& s : f->slots) {
+        Ctx* l = reinterpret_cast<Ctx*>(s.lane);
+        if (!l) continue;
+        (void)hipStreamSynchronize(l->stream);
+        if (l->aux_stream) (void)hipStreamSynchronize(l->aux_stream);
+        pt_borrow_mesh(l, nullptr);
+        s.lane_version = 0;
+    }
 }
 }  // namespace rt
 
@@ -103,8 +139,13 @@ int rt_frames_configure(rt_ctx* ctx, uint32_t n_slots, uint32_t format) {
     const size_t px = (size_t)c->width * c->height;
     f->bytes = format == RT_FRAME_RGBA8 ? px * 4 : px * 3 * sizeof(float);
     f->slots.resize(n_slots);
-    hipError_t e = hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking);
+    // the copy stream gets the highest priority: priority levels have hardware queues of their own, so the
+    // read-backs never queue up behind a lane's kernels (streams of one priority share a handful of queues)
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    hipError_t e = hipStreamCreateWithPriority(&f->copy_stream, hipStreamNonBlocking, prio_high);
     for (Slot& s : f->slots) {
+        if (e == hipSuccess && (rt_create(&s.lane, c->device) != RT_OK || rt_resize(s.lane, c->width, c->height, c->ratio) != RT_OK)) e = hipErrorOutOfMemory;
         if (e == hipSuccess) e = hipMalloc((void**)&s.d_rgb, px * 3 * sizeof(float));
         if (e == hipSuccess && format == RT_FRAME_RGBA8) e = hipMalloc((void**)&s.d_rgba, px * 4);
         if (e == hipSuccess) e = hipHostMalloc(&s.h_pixels, f->bytes, hipHostMallocDefault);
@@ -122,13 +163,13 @@ int rt_frames_configure(rt_ctx* ctx, uint32_t n_slots, uint32_t format) {
 int rt_frame_submit(rt_ctx* ctx, uint32_t slot, const float rot[4], const float pos[3], uint32_t spp) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return RT_ERR_INVALID;
-    return submit(c, slot, [&](float* dst) { return rt_render_device(ctx, rot, pos, spp, dst, 0); });
+    return submit(c, slot, [&](rt_ctx* lane, float* dst) { return rt_render_device(lane, rot, pos, spp, dst, 0); });
 }
 
 int rt_frame_submit_pt(rt_ctx* ctx, uint32_t slot, const float rot[4], const float pos[3], const rt_pt_params* params) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return RT_ERR_INVALID;
-    return submit(c, slot, [&](float* dst) { return rt_render_pt_device(ctx, rot, pos, params, dst, 0); });
+    return submit(c, slot, [&](rt_ctx* lane, float* dst) { return rt_render_pt_device(lane, rot, pos, params, dst, 0); });
 }
 
 int rt_frame_wait(rt_ctx* ctx, uint32_t slot, const void** pixels, size_t* bytes) {

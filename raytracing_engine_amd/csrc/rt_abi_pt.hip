@@ -46,6 +46,11 @@ void free_wavefront(PtData& pt) {
 }
 
 void free_mesh(PtData& pt) {
+    if (pt.borrowed_mesh) {  // another context owns the arrays
+        pt.d_nodes = pt.d_tris = pt.d_albedo = pt.d_emission = nullptr;
+        pt.d_lights = nullptr;
+        pt.borrowed_mesh = false;
+    }
     dfree(pt.d_nodes);
     dfree(pt.d_tris);
     dfree(pt.d_albedo);
@@ -188,7 +193,11 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     uint64_t cam = 0, bnc = 0, shd = 0;
     uint32_t launches_closest = 0, launches_shadow = 0;
     // per-stage timing needs the stages back to back on one stream
-    const bool overlap = !tm.on && !prm->tune_no_overlap && c->aux_stream != nullptr;
+    // the auxiliary stream exists from the first path-B frame that wants it: streams are dealt onto a few
+    // hardware queues in creation order, and a context that only renders path A should not occupy two
+    const bool want_overlap = !tm.on && !prm->tune_no_overlap && pt.n_lights != 0;
+    if (want_overlap && !c->aux_stream) RT_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    const bool overlap = want_overlap && c->aux_stream != nullptr;
     bool shadow_pending = false;
     if (overlap && !pt.ev_shaded) {
         RT_HIP(c, hipEventCreateWithFlags(&pt.ev_shaded, hipEventDisableTiming));
@@ -327,6 +336,35 @@ void pt_free(Ctx* c) {
     if (c->pt.ev_shadowed) (void)hipEventDestroy(c->pt.ev_shadowed);
     c->pt.ev_shaded = c->pt.ev_shadowed = nullptr;
 }
+
+// `lane` renders with `owner`'s device mesh (read-only during rendering); the owner tells its lanes
+// before it frees or replaces the mesh (frames_drop_mesh).
+void pt_borrow_mesh(Ctx* lane, const Ctx* owner) {  // owner == nullptr: only forget what was borrowed
+    PtData& d = lane->pt;
+    free_mesh(d);
+    if (!owner || !owner->pt.n_tris) return;
+    const PtData& s = owner->pt;
+    d.borrowed_mesh = true;
+    d.n_tris = s.n_tris;
+    d.n_nodes = s.n_nodes;
+    d.n_lights = s.n_lights;
+    d.bvh_depth = s.bvh_depth;
+    d.bvh_build_ms = s.bvh_build_ms;
+    d.bvh_pad = s.bvh_pad;
+    d.d_nodes = s.d_nodes;
+    d.d_tris = s.d_tris;
+    d.d_albedo = s.d_albedo;
+    d.d_emission = s.d_emission;
+    d.d_lights = s.d_lights;
+    d.stack_need = s.stack_need;
+    d.stats = rt_pt_stats{};
+    d.stats.n_tris = s.n_tris;
+    d.stats.n_nodes = s.n_nodes;
+    d.stats.bvh_depth = s.bvh_depth;
+    d.stats.stack_need = s.stack_need;
+    d.stats.n_lights = s.n_lights;
+    d.stats.bvh_build_ms = s.bvh_build_ms;
+}
 }  // namespace rt
 
 extern "C" {
@@ -356,8 +394,11 @@ int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const floa
         if (!std::isfinite(verts[i])) return c->fail(RT_ERR_INVALID, "vertex data is not finite at float %zu", i);
     if (int rc = bind(c)) return rc;
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->aux_stream) RT_HIP(c, hipStreamSynchronize(c->aux_stream));
+    rt::frames_drop_mesh(c);  // frame-slot lanes render with this mesh
     PtData& pt = c->pt;
     free_mesh(pt);
+    c->state_version++;
 
     const size_t n = n_tris;
     // spec §6.1: edges are formed once, in fp32

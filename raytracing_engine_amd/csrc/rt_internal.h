@@ -167,6 +167,7 @@ struct PtFrame {
 };
 
 struct PtData {  // device residency of one mesh + the wavefront buffers
+    bool borrowed_mesh = false;  // the mesh arrays belong to another context (frame-slot lanes share their parent's mesh)
     uint32_t n_tris = 0, n_nodes = 0, n_lights = 0, bvh_depth = 0;
     float bvh_build_ms = 0.0f, bvh_pad = 0.0f;
     float4* d_nodes = nullptr;
@@ -219,6 +220,7 @@ struct Ctx {
     PtData pt;
     int n_cus = 256;
     void* frames = nullptr;  // frames-in-flight slots (rt_abi_frames.hip)
+    uint64_t state_version = 1;  // bumped by rt_set_config / rt_set_scene / rt_set_mesh: frame-slot lanes re-sync on submit
     void* comm = nullptr;  // ncclComm_t once rt_comm_init ran (rt_abi_comm.hip)
     uint32_t comm_rank = 0, comm_ranks = 1;
 
@@ -239,7 +241,9 @@ struct Ctx {
         if (e_ != hipSuccess) return (ctx)->fail(RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-void frames_free(Ctx* c);  // rt_abi_frames.hip: waits for frames in flight, releases every slot
+void frames_free(Ctx* c);          // rt_abi_frames.hip: waits for frames in flight, releases every slot
+void frames_drop_mesh(Ctx* c);     // rt_abi_frames.hip: the parent's mesh is about to be freed: idle the lanes, forget the borrowed arrays
+void pt_borrow_mesh(Ctx* lane, const Ctx* owner);  // rt_abi_pt.hip: lane renders with owner's device mesh
 
 // path_a.hip
 int launch_cone_level(Ctx* c, const SphereSet& spheres, uint32_t n_obj, const ConeLevelParams& p, const float* parent,

@@ -89,3 +89,32 @@ def test_error_behaviour(r):
     r.frames_configure(2, r.FRAME_F32)
     r.frame_submit(0)
     assert r.frame_wait(0).shape == (H, W, 3)
+
+
+def test_lanes_follow_scene_config_and_mesh_changes(r):
+    """Every slot renders on a lane of its own (child context; the parent's configuration, scene and - borrowed -
+    mesh as of the submit): changing any of them between submits must show up in the next frames, and
+    replacing the mesh while lanes still hold the old one must be safe."""
+    r.set_scene(R.default_scene())
+    r.frames_configure(2, r.FRAME_F32)
+    r.frame_submit(0, spp=1)
+    a = r.frame_wait(0)
+    r.set_scene(R.cornell_scene())
+    cfg = r.default_config()
+    cfg.render_dist = 500.0
+    r.set_config(cfg)
+    r.frame_submit(1, spp=1)
+    r.frame_submit(0, spp=1)
+    b1, b0 = r.frame_wait(1), r.frame_wait(0)
+    want = r.render(spp=1)
+    assert np.array_equal(b0, want) and np.array_equal(b1, want) and not np.array_equal(a, want)
+    r.set_config(r.default_config())
+    prm = r.pt_params(spp=1, bounces=1, seed=4, sky=(0.1, 0.1, 0.1))
+    for mesh, pos in [(R.scenes.cornell_tri_scene(), (0.0, 1.0, 0.0)), (R.scenes.soup_scene(2000, seed=3, edge=1.0), (0.0, 0.0, 0.0))]:
+        r.set_mesh(*mesh)  # the lanes drop the previous mesh before it is freed
+        r.frame_submit(0, pos=pos, pt_params=prm)
+        r.frame_submit(1, pos=pos, pt_params=prm)
+        got0, got1 = r.frame_wait(0), r.frame_wait(1)
+        want = r.render_pt(pos=pos, params=prm)
+        assert np.array_equal(got0, want) and np.array_equal(got1, want)
+    r.set_scene(R.cornell_scene())

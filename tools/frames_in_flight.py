@@ -36,8 +36,9 @@ def sync_loop(cs):
 
 
 def pipelined(fmt):
+    r.frames_configure(a.slots, fmt)  # slots (and their render lanes) are set up once, like a swapchain
+
     def run(cs):
-        r.frames_configure(a.slots, fmt)
         n = a.slots
         for k, (rot, pos) in enumerate(cs):
             r.frame_submit(k % n, rot, pos, spp=a.spp)
