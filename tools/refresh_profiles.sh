@@ -6,12 +6,16 @@
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof
+rm -rf $O
 mkdir -p $O
 cd /tmp
 export TMPDIR=/tmp
 for W in tri1m_1080p_4spp terrain1m_1080p_4spp spheres8_1080p_4spp; do
     python3 $R/bench.py --workload $W > $O/bench_$W.json 2> $O/bench_$W.err
-    rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- python3 $R/bench.py --workload $W --no-traffic > /dev/null 2>&1
+    # kernel durations: one frame at a time (what roofline.avg_kernel_ms measures, with HIP events, on lane 0 alone) ...
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- python3 $R/bench.py --workload $W --frames-in-flight 1 --no-traffic --no-cpu-baseline > $O/bench_1lane_$W.json 2> /dev/null
+    # ... and the default command (three frame lanes: kernels of different frames overlap and stretch each other)
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3_$W -- python3 $R/bench.py --workload $W --no-traffic --no-cpu-baseline > /dev/null 2>&1
     echo "done $W"
 done
 P="python3 $R/bench.py --traffic-child --workload tri1m_1080p_4spp"
