@@ -91,12 +91,17 @@ int ensure_wavefront(Ctx* c, uint64_t n_paths, uint64_t n_slots) {
 // Traversal stack + persistent grid.  The first lds_cap entries of every lane's stack live in LDS
 // (8-byte entries: 2 x lds_cap KiB per 256-thread workgroup), which bounds residency at floor(160 KiB / that) workgroups
 // per CU, 8 at most (32 waves per CU); the rest of the builder's worst case spills to global memory.
-int stack_config(Ctx* c, uint32_t tune_lds, uint32_t tune_blocks, rt::StackCfg* sk, uint32_t* grid) {
+int stack_config(Ctx* c, uint32_t tune_lds, uint32_t tune_blocks, uint64_t n_paths, rt::StackCfg* sk, uint32_t* grid) {
     PtData& pt = c->pt;
     const uint32_t need = std::max<uint32_t>(pt.stack_need, 1u);
     const uint32_t lds_cap = std::min<uint32_t>(need, tune_lds ? std::min<uint32_t>(tune_lds, 80u) : 8u);
     const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 80u / lds_cap));  // 2 KiB per entry per workgroup
-    const uint32_t blocks_per_cu = tune_blocks ? std::min<uint32_t>(tune_blocks, fit) : fit;
+    // Few paths (a rank's small share of a frame): fewer resident waves.  Every lane of the grid takes a ray
+    // at once, so with ~2 rays per lane the rays in flight span half the frame instead of a compact window
+    // and the short launches are all ramp and tail; about four rays per lane and more measured best
+    // (1/8 of the headline frame: 2.87 -> 2.62 ms with 4 instead of 8 workgroups per CU).
+    const uint32_t by_load = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(3, (n_paths + (uint64_t)c->n_cus * 1024 - 1) / ((uint64_t)c->n_cus * 1024)));
+    const uint32_t blocks_per_cu = tune_blocks ? std::min<uint32_t>(tune_blocks, fit) : std::min(fit, by_load);
     *grid = (uint32_t)c->n_cus * blocks_per_cu;
     sk->lds_cap = (int)lds_cap;
     sk->spill_cap = (int)(need - lds_cap);
@@ -180,7 +185,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     const bool count = prm->count_traversal != 0;
     rt::StackCfg stack_cap{};
     uint32_t grid_persistent = 0;
-    if (int rc = stack_config(c, prm->tune_lds_stack, prm->tune_blocks_per_cu, &stack_cap, &grid_persistent)) return rc;
+    if (int rc = stack_config(c, prm->tune_lds_stack, prm->tune_blocks_per_cu, n_slots * spp_batch, &stack_cap, &grid_persistent)) return rc;
     // low byte: idle lanes that trigger a refill; next byte (tuning): inner steps per round
     const uint32_t refill_min = (prm->tune_refill_min & 0xffu ? std::min<uint32_t>(prm->tune_refill_min & 0xffu, 64u) : 24u) | (prm->tune_refill_min & 0xff00u);
     const uint32_t grid_stride = (uint32_t)c->n_cus * 2u;  // 1024-thread workgroups, grid-stride
@@ -505,7 +510,7 @@ int rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t
     if (!rc && e == hipSuccess) e = hipMemcpy(d_d, dirs, nb * 12, hipMemcpyHostToDevice);
     rt::StackCfg sk{};
     uint32_t grid = 0;
-    if (!rc) rc = stack_config(c, 0, 0, &sk, &grid);
+    if (!rc) rc = stack_config(c, 0, 0, (uint64_t)n, &sk, &grid);
     if (!rc && e == hipSuccess) rc = rt::launch_pt_trace_rays(c, scene_view(c->pt), d_o, d_d, n, any_hit, d_t, d_i, sk, std::min<uint32_t>(grid, (n + 255u) / 256u));
     if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (!rc && e == hipSuccess) e = hipMemcpy(t_out, d_t, nb * 4, hipMemcpyDeviceToHost);

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Per-rank cost of a 1/N tile share of the headline frame on ONE GPU (rank 0 and rank N-1 of N emulated
-with rt_set_partition): what strong scaling can reach before the exchange.  python tools/partition_scaling.py"""
+"""Per-rank cost of a 1/N tile share of the headline frame on ONE GPU (rank 0 of N emulated with
+rt_set_partition), for 1 .. --lanes frames in flight (contexts taking the frames round-robin, as bench.py
+does): what strong scaling can reach before the exchange.   python tools/partition_scaling.py [--lanes 6]"""
+import argparse
 import os
 import sys
 import time
@@ -10,30 +12,38 @@ import torch  # noqa: E402
 
 import raytracing_engine_amd as R  # noqa: E402
 
-r = R.Renderer(0)
-r.set_mesh(*R.scenes.soup_scene(1_000_000, seed=1, edge=0.08))
-r.resize(1920, 1080)
-prm = r.pt_params(spp=4, bounces=1, seed=1, sky=(0.2, 0.2, 0.25))
-buf = torch.empty(1920 * 1088 * 3 + 64 * 64 * 3 * 600, dtype=torch.float32, device="cuda")
-base = None
+ap = argparse.ArgumentParser()
+ap.add_argument("--lanes", type=int, default=6)
+ap.add_argument("--frames", type=int, default=24)
+a = ap.parse_args()
+mesh = R.scenes.soup_scene(1_000_000, seed=1, edge=0.08)
+rs, bufs = [], []
+for _ in range(a.lanes):
+    r = R.Renderer(0)
+    r.set_mesh(*mesh)
+    r.resize(1920, 1080)
+    rs.append(r)
+    bufs.append(torch.empty(1920 * 1088 * 3 + 64 * 64 * 3 * 600, dtype=torch.float32, device="cuda"))
+prm = rs[0].pt_params(spp=4, bounces=1, seed=1, sky=(0.2, 0.2, 0.25))
+
+
+def run(lanes, n_ranks):
+    for r in rs:
+        r.set_partition(0, n_ranks)
+    for i in range(2 * lanes):
+        rs[i % lanes].render_pt_device((0, 0, 0, 1), (0, 0, 0), prm, bufs[i % lanes].data_ptr(), True)
+    for r in rs:
+        r.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.frames):
+        rs[i % lanes].render_pt_device((0, 0, 0, 1), (0, 0, 0), prm, bufs[i % lanes].data_ptr(), True)
+    for r in rs:
+        r.synchronize()
+    return (time.perf_counter() - t0) / a.frames * 1e3
+
+
+base = run(1, 1)
+print(f"whole frame, one lane: {base:.3f} ms")
 for n in (1, 2, 4, 8):
-    for rank in ((0,) if n == 1 else (0, n - 1)):
-        r.set_partition(rank, n)
-        for _ in range(3):
-            r.render_pt_device((0, 0, 0, 1), (0, 0, 0), prm, buf.data_ptr(), True)
-        r.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            r.render_pt_device((0, 0, 0, 1), (0, 0, 0), prm, buf.data_ptr(), True)
-        r.synchronize()
-        dt = (time.perf_counter() - t0) / 20 * 1e3
-        base = base or dt
-        cfg = r.default_config()
-        cfg.profile_stages = 1
-        r.set_config(cfg)
-        r.render_pt((0, 0, 0, 1), (0, 0, 0), params=prm)
-        st = r.pt_stats()
-        cfg.profile_stages = 0
-        r.set_config(cfg)
-        stages = " ".join(f"{k[3:]}={st[k]:.3f}" for k in ("ms_generate", "ms_trace_closest", "ms_shade", "ms_trace_shadow", "ms_resolve"))
-        print(f"ranks {n} rank {rank}: {dt:7.3f} ms/step (ideal {base / n:6.3f}, efficiency {base / n / dt:.2f})   stages, serialised: {stages}", flush=True)
+    row = [run(lanes, n) for lanes in range(1, a.lanes + 1)]
+    print(f"1/{n} of the frame (ideal {base / n:6.3f} ms): " + "  ".join(f"{lanes} lane{'s' if lanes > 1 else ' '} {t:6.3f} ({base / n / t:.2f})" for lanes, t in enumerate(row, 1)), flush=True)

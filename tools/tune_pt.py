@@ -21,6 +21,7 @@ ap.add_argument("--k", default="0")
 ap.add_argument("--gate", default="0")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--scene", default="soup")
+ap.add_argument("--ranks", type=int, default=1, help="render rank 0's share of an N-rank tile split")
 ap.add_argument("--count", action="store_true", help="also print traversal counters per configuration")
 a = ap.parse_args()
 
@@ -29,6 +30,7 @@ mesh = (R.scenes.soup_scene(a.tris, seed=1, edge=a.edge) if a.scene == "soup" el
         else R.scenes.cornell_tri_scene())
 r.set_mesh(*mesh)
 r.resize(1920, 1080)
+r.set_partition(0, a.ranks)
 cfg = r.default_config()
 cfg.profile_stages = 1
 r.set_config(cfg)
