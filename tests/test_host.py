@@ -151,3 +151,11 @@ def test_two_rank_gather_over_gloo(tmp_path):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
     assert "OK" in outs[0][0]
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" check: __graft_entry__.build() compiles the library, the oracle and the host
+    CLI (incremental here) and verifies the ABI version the loaded library reports."""
+    import __graft_entry__ as g
+
+    g.build()
