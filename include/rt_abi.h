@@ -217,13 +217,13 @@ typedef struct rt_pt_params {
     uint32_t count_traversal; /* 1: count BVH nodes fetched / triangles tested (rt_pt_stats) */
     uint32_t max_paths;       /* cap on paths in flight per pass (0 = default 2^25); spp is split into passes */
     uint32_t tune_refill_min;    /* tuning: idle lanes per wave that trigger a refill (0 = default 24; byte 1: triangle tests per round, 0 = 1) */
-    uint32_t tune_blocks_per_cu; /* tuning: persistent workgroups per CU (0 = as many as the LDS stacks allow) */
+    uint32_t tune_blocks_per_cu; /* tuning: persistent workgroups per CU (0 = as many as the LDS stacks allow, fewer for few paths) */
     uint32_t tune_lds_stack;     /* tuning: traversal-stack entries kept in LDS per lane (0 = default 8), rest spills */
     uint32_t tune_no_overlap;    /* tuning: 1 = keep the shadow kernel on the main stream (no overlap with the next closest-hit kernel) */
 } rt_pt_params;
 
 typedef struct rt_pt_stats {
-    uint32_t n_tris, n_nodes, bvh_depth, n_lights; /* n_nodes / bvh_depth of the 4-wide BVH */
+    uint32_t n_tris, n_nodes, bvh_depth, n_lights; /* n_nodes / bvh_depth of the compressed 8-wide BVH */
     uint32_t stack_need;       /* worst-case traversal stack entries for this BVH */
     float bvh_build_ms;
     uint32_t stack_overflow;   /* must be 0: traversal stack never exceeded */
@@ -238,7 +238,8 @@ typedef struct rt_pt_stats {
 
 int rt_default_pt_params(rt_pt_params* p);
 /* verts: n_tris*9 (v0,v1,v2), albedo: n_tris*3, emission: n_tris*3 (any component > 0 = light).
- * Uploads the mesh and builds the BVH on the host (binned SAH).  Host pointers, copied. */
+ * Uploads the mesh and builds the BVH on the host (binned SAH -> compressed 8-wide nodes, threaded; the result does
+ * not depend on the thread count).  Host pointers, copied. */
 int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const float* emission, uint32_t n_tris);
 /* Synchronous path-traced frame of the current view (rt_resize) into host memory. */
 int rt_render_pt(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, float* rgb_out);
