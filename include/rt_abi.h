@@ -179,6 +179,9 @@ int rt_read_level(rt_ctx* ctx, uint32_t level, float* out, uint32_t* w, uint32_t
 int rt_read_rgba8(rt_ctx* ctx, uint8_t* rgba_out);
 
 int rt_get_stats(const rt_ctx* ctx, rt_stats* stats);
+/* Test hook: the kernels take square roots with a shortened correctly rounded sequence; this runs it against the
+ * compiler's IEEE sqrt on the device for every one of the 2^32 fp32 inputs and returns how many differ (0). */
+int rt_selftest_math(rt_ctx* ctx, uint64_t* mismatches);
 
 /* Frames in flight - the reference's swapchain loop (src/main.rs:664-667, 882-927: one fence per
  * swapchain image; a frame waits for its image's fence, is recorded, submitted behind the previous

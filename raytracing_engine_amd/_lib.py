@@ -118,6 +118,7 @@ PROTOTYPES = {
     "rt_render_pt": (C.c_int, [_vp, _fp, _fp, C.POINTER(PtParams), _fp]),
     "rt_render_pt_device": (C.c_int, [_vp, _fp, _fp, C.POINTER(PtParams), _vp, C.c_int]),
     "rt_get_pt_stats": (C.c_int, [_vp, C.POINTER(PtStats)]),
+    "rt_selftest_math": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "rt_frames_configure": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "rt_frame_submit": (C.c_int, [_vp, C.c_uint32, _fp, _fp, C.c_uint32]),
     "rt_frame_submit_pt": (C.c_int, [_vp, C.c_uint32, _fp, _fp, C.POINTER(PtParams)]),

@@ -335,6 +335,20 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
     }
 }
 
+// ---- self test of the arithmetic contract's sqrt ------------------------------------------------
+// every one of the 2^32 fp32 bit patterns: sqrt_cr must return the bits of the compiler's correctly rounded sqrt
+__global__ __launch_bounds__(256) void selftest_sqrt_kernel(unsigned long long* __restrict__ mismatches) {
+    unsigned long long bad = 0;
+    for (uint32_t k = 0; k < 256u; k++) {
+        const uint32_t bits = (blockIdx.x * 256u + threadIdx.x) * 256u + k;
+        const float x = __uint_as_float(bits);
+        const float a = sqrt_cr(x), b = __builtin_sqrtf(x);
+        const bool same = (a != a && b != b) || __float_as_uint(a) == __float_as_uint(b);
+        bad += same ? 0u : 1u;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // ---- fused pyramid kernel -------------------------------------------------------------------------
 // The reference records one dispatch per pyramid level (src/main.rs:300-316) because Vulkan needs a
 // barrier between levels.  A pixel's chain of ancestors is private to its 32x32 neighbourhood, so on
@@ -532,6 +546,12 @@ int launch_pyramid_fused(Ctx* c, const SphereSet& S, uint32_t n_obj, const Pyram
         case 7: pyramid_launch_n<7>(c->stream, grid, S, fp); break;
         default: pyramid_launch_n<8>(c->stream, grid, S, fp); break;
     }
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_selftest_sqrt(Ctx* c, unsigned long long* mismatches_dev) {
+    hipLaunchKernelGGL(selftest_sqrt_kernel, dim3(1u << 16), dim3(256), 0, c->stream, mismatches_dev);  // 65536 x 256 x 256 = 2^32 inputs
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }

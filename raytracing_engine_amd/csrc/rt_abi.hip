@@ -582,6 +582,25 @@ int rt_read_rgba8(rt_ctx* ctx, uint8_t* rgba_out) {
     return RT_OK;
 }
 
+int rt_selftest_math(rt_ctx* ctx, uint64_t* mismatches) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return RT_ERR_INVALID;
+    if (!mismatches) return c->fail(RT_ERR_INVALID, "mismatches is NULL");
+    if (int rc = bind(c)) return rc;
+    unsigned long long* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof *d) != hipSuccess) return c->fail(RT_ERR_OOM, "self-test counter");
+    hipError_t e = hipMemsetAsync(d, 0, sizeof *d, c->stream);
+    int rc = e == hipSuccess ? rt::launch_selftest_sqrt(c, d) : RT_OK;
+    unsigned long long h = 0;
+    if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (!rc && e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) return c->fail(RT_ERR_HIP, "math self-test: %s", hipGetErrorString(e));
+    *mismatches = h;
+    return RT_OK;
+}
+
 int rt_get_stats(const rt_ctx* ctx, rt_stats* stats) {
     const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
     if (!c || !stats) return RT_ERR_INVALID;

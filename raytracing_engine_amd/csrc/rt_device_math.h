@@ -7,7 +7,7 @@
 // (-fhip-fp32-correctly-rounded-divide-sqrt).
 //
 //   dot(a,b)     = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
-//   length(a)    = sqrt(dot(a,a))
+//   length(a)    = sqrt(dot(a,a))          (sqrt_cr below: the same correctly rounded value, fewer instructions)
 //   normalize(a) = a * (1 / length(a))
 //   cross(a,b).x = fma(a.y,b.z, -(a.z*b.y))   (cyclic)
 #pragma once
@@ -29,7 +29,25 @@ __device__ __forceinline__ v3 fma3(v3 a, float s, v3 b) {
     return v3{__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z)};
 }
 __device__ __forceinline__ float dot(v3 a, v3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
-__device__ __forceinline__ float length(v3 a) { return __builtin_sqrtf(dot(a, a)); }
+// Correctly rounded sqrt.  The compiler's sequence for __builtin_sqrtf is 16 instructions: scale tiny inputs
+// by 2^32, v_sqrt_f32, try the two neighbours of the estimate against the fma residuals, unscale, pass zero /
+// inf / NaN through.  For 2^-96 <= x < inf - every distance this library ever takes a root of - scaling and
+// pass-through do nothing, so those lanes run just the 9-instruction core (the same core, hence the same
+// bits); anything else takes the compiler's path.  Exhaustively compared over all 2^32 inputs by
+// rt_selftest_math (tests/test_gpu_path_a.py).
+__device__ __forceinline__ float sqrt_cr(float x) {
+    const uint32_t bits = __float_as_uint(x);
+    if (bits - 0x0f800000u < 0x7f800000u - 0x0f800000u) {
+        const float s = __builtin_amdgcn_sqrtf(x);  // v_sqrt_f32: within one ulp
+        const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+        const float e_below = __builtin_fmaf(-below, s, x), e_above = __builtin_fmaf(-above, s, x);
+        float r = e_below <= 0.0f ? below : s;
+        r = e_above > 0.0f ? above : r;
+        return r;
+    }
+    return __builtin_sqrtf(x);
+}
+__device__ __forceinline__ float length(v3 a) { return sqrt_cr(dot(a, a)); }
 __device__ __forceinline__ v3 normalize(v3 a) { return scale(a, 1.0f / length(a)); }
 __device__ __forceinline__ v3 cross(v3 a, v3 b) {
     return v3{__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)),

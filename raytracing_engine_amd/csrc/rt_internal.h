@@ -251,6 +251,7 @@ int launch_cone_level(Ctx* c, const SphereSet& spheres, uint32_t n_obj, const Co
 int launch_shade(Ctx* c, const ShadeSet& set, uint32_t n_obj, const ShadeParams& p, const float* depth, float* dst,
                  uint64_t* counters);
 int launch_pyramid_fused(Ctx* c, const SphereSet& spheres, uint32_t n_obj, const PyramidParams& fp);
+int launch_selftest_sqrt(Ctx* c, unsigned long long* mismatches_dev);
 int launch_detile(Ctx* c, const float* tiles, uint32_t n_ranks, uint32_t tiles_per_rank, float* rgb);
 int launch_to_rgba8(Ctx* c, const float* rgb, uint8_t* rgba, uint64_t n_pixels);
 

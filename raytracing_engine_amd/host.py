@@ -282,6 +282,12 @@ class Renderer:
         self._check(self._lib.rt_frame_poll(self._ctx, int(slot), C.byref(r)))
         return bool(r.value)
 
+    def selftest_math(self):
+        """Mismatches of the kernels' shortened sqrt against IEEE sqrt over all 2^32 fp32 inputs (0)."""
+        n = C.c_uint64()
+        self._check(self._lib.rt_selftest_math(self._ctx, C.byref(n)))
+        return int(n.value)
+
     def stats(self):
         s = Stats()
         self._check(self._lib.rt_get_stats(self._ctx, C.byref(s)))

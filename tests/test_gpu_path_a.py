@@ -335,3 +335,9 @@ def test_resize_and_rescene_cycles(renderer):
         rgb, depth = renderer.render(want_depth=True)
         ref = O.render_a(oracle_scene(scene), w, h)
         assert np.array_equal(depth, ref["levels"][-1]) and np.abs(rgb - ref["rgb"]).max() <= RGB_TOL
+
+
+def test_shortened_sqrt_is_correctly_rounded_for_every_input(renderer):
+    """rt_device_math.h sqrt_cr (the 9-instruction core of the compiler's 16-instruction IEEE sqrt for
+    2^-96 <= x < inf, the compiler's sequence otherwise) against __builtin_sqrtf on the device, all 2^32 inputs."""
+    assert renderer.selftest_math() == 0
