@@ -431,6 +431,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # set-up, not warm-up: every lane renders one frame so that its buffers exist (the first frame of a context
+    # allocates pyramid / wavefront state) whatever --warmup is; the lane rotation then starts at lane 0 again
+    for _ in range(n_lanes):
+        step()
+    fence()
+    state["i"] = 0
     for _ in range(args.warmup):
         step()
     fence()
