@@ -165,7 +165,11 @@ int rt_synchronize(rt_ctx* ctx);
  * after rendering tile-major, every rank calls rt_gather_tiles: the tiles go to rank 0 over RCCL
  * (grouped ncclSend/ncclRecv, one direct xGMI link per peer) on the context's stream, into
  * gathered_dev[rank][tiles_per_rank][64][64][3] on rank 0 (ignored elsewhere); rt_detile_device then
- * scatters them into the frame.  RCCL is loaded on first use. */
+ * scatters them into the frame.  tiles_dev holds the `owned` tiles of this rank (rt_tile_info), exactly
+ * what rt_render*_device(tile_major = 1) wrote; every rank sends its own count and the root receives each
+ * peer's own count, so uneven splits (510 tiles on 8 ranks: 64,64,64,64,64,64,63,63) read and write
+ * nothing beyond the owned tiles; tiles_per_rank (the same on every rank) must be >= ceil(tiles / n_ranks).
+ * RCCL is loaded on first use. */
 #define RT_COMM_ID_BYTES 128
 int rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]);
 int rt_comm_init(rt_ctx* ctx, const uint8_t id[RT_COMM_ID_BYTES], uint32_t rank, uint32_t n_ranks);
@@ -244,7 +248,10 @@ int rt_default_pt_params(rt_pt_params* p);
  * Uploads the mesh and builds the BVH on the host (binned SAH -> compressed 8-wide nodes, threaded; the result does
  * not depend on the thread count).  Host pointers, copied. */
 int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const float* emission, uint32_t n_tris);
-/* Synchronous path-traced frame of the current view (rt_resize) into host memory. */
+/* Synchronous path-traced frame of the current view (rt_resize) into host memory.
+ * Every |pos| component must be <= 32 x max(1, largest |vertex coordinate| of the mesh): that is the range
+ * over which the BVH's conservative box padding covers the fp32 rounding of the ray/box test (beyond it the
+ * frame could depend on the tree); RT_ERR_INVALID otherwise. */
 int rt_render_pt(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, float* rgb_out);
 /* Asynchronous device-side variant, same output layouts as rt_render_device. */
 int rt_render_pt_device(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, void* rgb_dev, int tile_major);

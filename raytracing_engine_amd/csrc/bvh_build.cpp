@@ -18,7 +18,9 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <exception>
 #include <limits>
+#include <system_error>
 #include <thread>
 
 #ifdef RT_BVH_TIMING
@@ -42,7 +44,10 @@ int host_threads() {
     return std::min(std::max(n, 1), 32);
 }
 
-// fn(i) for i in [0, n) on up to `threads` threads (contiguous chunks; fn must only touch item i's data)
+// fn(i) for i in [0, n) on up to `threads` threads (contiguous chunks; fn must only touch item i's data).
+// Nothing escapes a worker thread: an exception inside fn is carried back and rethrown here after every
+// thread has been joined, and chunks whose thread could not be created (std::system_error: thread or
+// process limit of the box) run on the calling thread, so the result never depends on how many started.
 template <typename F>
 void parallel_for(size_t n, int threads, size_t kMinPerThread, F fn) {
     const size_t want = std::min<size_t>((size_t)std::max(threads, 1), (n + kMinPerThread - 1) / kMinPerThread);
@@ -52,13 +57,27 @@ void parallel_for(size_t n, int threads, size_t kMinPerThread, F fn) {
     }
     std::vector<std::thread> pool;
     pool.reserve(want - 1);
+    std::vector<std::exception_ptr> errs(want);
     const size_t chunk = (n + want - 1) / want;
-    for (size_t t = 1; t < want; t++)
-        pool.emplace_back([=, &fn] {
+    auto run = [&](size_t t) noexcept {
+        try {
             for (size_t i = t * chunk; i < std::min(n, (t + 1) * chunk); i++) fn(i);
-        });
-    for (size_t i = 0; i < std::min(n, chunk); i++) fn(i);
+        } catch (...) {
+            errs[t] = std::current_exception();
+        }
+    };
+    for (size_t t = 1; t < want; t++) {
+        try {
+            pool.emplace_back(run, t);
+        } catch (const std::system_error&) {
+            break;
+        }
+    }
+    run(0);
+    for (size_t t = pool.size() + 1; t < want; t++) run(t);
     for (auto& th : pool) th.join();
+    for (auto& e : errs)
+        if (e) std::rethrow_exception(e);
 }
 
 struct Box {
@@ -280,14 +299,44 @@ struct Builder {
         Box b0 = range_box(first, mid), b1 = range_box(first + mid, count - mid);
         Sub s0, s1;
         bool forked = false;
-        if (spare_threads && count >= kForkMin && spare_threads->fetch_sub(1) > 0) {
-            forked = true;
-            std::thread left([&] { s0 = build(first, mid, depth + 1, me + 1u); });
-            s1 = build(first + mid, count - mid, depth + 1, me + mid);
-            left.join();
-            spare_threads->fetch_add(1);
-        } else if (spare_threads && count >= kForkMin) {
-            spare_threads->fetch_add(1);  // undo the failed reservation
+        if (spare_threads && count >= kForkMin) {
+            if (spare_threads->fetch_sub(1) > 0) {
+                std::exception_ptr left_err;
+                std::thread left;
+                try {
+                    left = std::thread([&]() noexcept {
+                        try {
+                            s0 = build(first, mid, depth + 1, me + 1u);
+                        } catch (...) {
+                            left_err = std::current_exception();
+                        }
+                    });
+                    forked = true;
+                } catch (const std::system_error&) {  // thread limit reached: this subtree is built on the calling thread
+                }
+                if (forked) {
+                    {
+                        struct Join {  // the right-hand build may throw while `left` is still running
+                            std::thread& t;
+                            ~Join() {
+                                if (t.joinable()) t.join();
+                            }
+                        } join{left};
+                        try {
+                            s1 = build(first + mid, count - mid, depth + 1, me + mid);
+                        } catch (...) {
+                            spare_threads->fetch_add(1);
+                            throw;
+                        }
+                    }
+                    spare_threads->fetch_add(1);
+                    if (left_err) std::rethrow_exception(left_err);
+                } else {
+                    spare_threads->fetch_add(1);
+                }
+            } else {
+                spare_threads->fetch_add(1);  // undo the failed reservation
+            }
         }
         if (!forked) {
             s0 = build(first, mid, depth + 1, me + 1u);

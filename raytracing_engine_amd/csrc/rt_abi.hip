@@ -43,6 +43,8 @@ void free_frame(Ctx* c) {
     }
     if (c->d_rgb) (void)hipFree(c->d_rgb);
     c->d_rgb = nullptr;
+    if (c->d_rgba8) (void)hipFree(c->d_rgba8);
+    c->d_rgba8 = nullptr;
     c->level_batch = 0;
     c->last_image = 0;
     c->frame_valid = false;
@@ -571,14 +573,14 @@ int rt_read_rgba8(rt_ctx* ctx, uint8_t* rgba_out) {
     if (!c->frame_valid) return c->fail(RT_ERR_STATE, "no frame rendered yet");
     if (int rc = bind(c)) return rc;
     const uint64_t n = (uint64_t)c->width * c->height;
-    uint8_t* d = nullptr;
-    if (hipMalloc((void**)&d, n * 4) != hipSuccess) return c->fail(RT_ERR_OOM, "rgba8 staging buffer");
-    int rc = rt::launch_to_rgba8(c, c->d_rgb, d, n);
-    hipError_t e = rc ? hipSuccess : hipStreamSynchronize(c->stream);
-    if (!rc && e == hipSuccess) e = hipMemcpy(rgba_out, d, n * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    if (rc) return rc;
-    if (e != hipSuccess) return c->fail(RT_ERR_HIP, "rgba8 read-back: %s", hipGetErrorString(e));
+    // staging buffer of the view's size, kept until rt_resize / rt_destroy: this call sits in a per-frame loop
+    if (!c->d_rgba8 && hipMalloc((void**)&c->d_rgba8, n * 4) != hipSuccess) {
+        c->d_rgba8 = nullptr;
+        return c->fail(RT_ERR_OOM, "rgba8 staging buffer");
+    }
+    if (int rc = rt::launch_to_rgba8(c, c->d_rgb, c->d_rgba8, n)) return rc;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(rgba_out, c->d_rgba8, n * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -117,23 +117,32 @@ int rt_gather_tiles(rt_ctx* ctx, const void* tiles_dev, void* gathered_dev, uint
     if (!c->comm) return c->fail(RT_ERR_STATE, "rt_comm_init has not been called");
     if (!tiles_dev || tiles_per_rank == 0) return c->fail(RT_ERR_INVALID, "NULL tile buffer or tiles_per_rank = 0");
     if (c->comm_rank == 0 && !gathered_dev) return c->fail(RT_ERR_INVALID, "rank 0 needs the gather buffer");
+    if (!c->width) return c->fail(RT_ERR_STATE, "rt_resize has not been called");
+    // Every rank sends exactly the tiles it owns (tiles_dev holds `owned` tiles, as rt_render*_device(tile_major)
+    // documents: with 510 tiles on 8 ranks, ranks 6 and 7 own 63, not ceil(510/8) = 64) and the root receives
+    // each peer's own count into that peer's block of tiles_per_rank tiles; pad tiles are never touched.
+    const uint32_t total = c->part.tiles_x * c->part.tiles_y, n = c->comm_ranks;
+    auto owned_by = [&](uint32_t rank) { return total > rank ? (total - rank + n - 1u) / n : 0u; };
+    if (tiles_per_rank < owned_by(0)) return c->fail(RT_ERR_INVALID, "tiles_per_rank %u < %u tiles owned by rank 0", tiles_per_rank, owned_by(0));
     Rccl* r = rccl();
     RT_HIP(c, hipSetDevice(c->device));
-    const size_t count = (size_t)tiles_per_rank * RT_TILE * RT_TILE * 3;  // floats per rank
+    const size_t tile_floats = (size_t)RT_TILE * RT_TILE * 3;
+    const size_t block = (size_t)tiles_per_rank * tile_floats;  // floats per rank in gathered_dev
     ncclComm_t comm = static_cast<ncclComm_t>(c->comm);
     ncclResult_t e = r->GroupStart();
     if (e != ncclSuccess) return nccl_fail(c, "ncclGroupStart", e);
     if (c->comm_rank == 0) {
         float* dst = static_cast<float*>(gathered_dev);
-        for (uint32_t peer = 1; peer < c->comm_ranks && e == ncclSuccess; peer++) e = r->Recv(dst + (size_t)peer * count, count, ncclFloat32, (int)peer, comm, c->stream);
-    } else {
-        e = r->Send(tiles_dev, count, ncclFloat32, 0, comm, c->stream);
+        for (uint32_t peer = 1; peer < n && e == ncclSuccess; peer++)
+            if (owned_by(peer)) e = r->Recv(dst + (size_t)peer * block, owned_by(peer) * tile_floats, ncclFloat32, (int)peer, comm, c->stream);
+    } else if (owned_by(c->comm_rank)) {
+        e = r->Send(tiles_dev, owned_by(c->comm_rank) * tile_floats, ncclFloat32, 0, comm, c->stream);
     }
     const ncclResult_t e2 = r->GroupEnd();
     if (e != ncclSuccess) return nccl_fail(c, "ncclSend/ncclRecv", e);
     if (e2 != ncclSuccess) return nccl_fail(c, "ncclGroupEnd", e2);
-    if (c->comm_rank == 0 && gathered_dev != tiles_dev)  // the root's own tiles: a device-to-device copy on the same stream
-        RT_HIP(c, hipMemcpyAsync(gathered_dev, tiles_dev, count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    if (c->comm_rank == 0 && gathered_dev != tiles_dev && owned_by(0))  // the root's own tiles: a device-to-device copy on the same stream
+        RT_HIP(c, hipMemcpyAsync(gathered_dev, tiles_dev, owned_by(0) * tile_floats * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return RT_OK;
 }
 

@@ -5,6 +5,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
+#include <system_error>
 #include <vector>
 
 #include "bvh_build.h"
@@ -17,6 +20,7 @@ namespace {
 
 constexpr uint64_t kMaxPathsInFlight = 1ull << 25;  // 33.5 M paths = 4.3 GB of wavefront state
 constexpr uint32_t kMaxBounces = 15;
+constexpr float kCameraReach = 32.0f;  // camera |coordinate| limit in units of the mesh's largest |coordinate| (render_pt_common)
 
 int bind(Ctx* c) {
     RT_HIP(c, hipSetDevice(c->device));
@@ -140,27 +144,35 @@ uint32_t owned_tiles(const rt::Partition& p) {
 struct StageTimer {  // HIP-event pairs around launches, summed per stage after the frame
     Ctx* c;
     bool on;
-    std::vector<hipEvent_t>& pool;
+    std::vector<hipEvent_t>& pool;  // the context's own events: created after hipSetDevice(c->device), freed by pt_free
     std::vector<std::pair<int, size_t>> marks;  // stage, index of begin event
     size_t used = 0;
+    hipError_t err = hipSuccess;  // first failure of an event call (reported by the frame)
     hipEvent_t next() {
         if (used == pool.size()) {
             hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            const hipError_t rc = hipEventCreate(&e);
+            if (rc != hipSuccess) {
+                if (err == hipSuccess) err = rc;
+                return nullptr;
+            }
             pool.push_back(e);
         }
         return pool[used++];
     }
+    void record() {
+        hipEvent_t e = next();
+        if (!e) return;
+        const hipError_t rc = hipEventRecord(e, c->stream);
+        if (rc != hipSuccess && err == hipSuccess) err = rc;
+    }
     void begin(int stage) {
         if (!on) return;
         marks.push_back({stage, used});
-        hipEvent_t e = next();
-        if (e) (void)hipEventRecord(e, c->stream);
+        record();
     }
     void end() {
-        if (!on) return;
-        hipEvent_t e = next();
-        if (e) (void)hipEventRecord(e, c->stream);
+        if (on) record();
     }
 };
 
@@ -170,6 +182,17 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     if (!c->pt.n_tris) return c->fail(RT_ERR_STATE, "rt_set_mesh has not been called");
     if (!c->width) return c->fail(RT_ERR_STATE, "rt_resize has not been called");
     if (prm->spp == 0 || prm->bounces > kMaxBounces) return c->fail(RT_ERR_INVALID, "spp %u / bounces %u out of range", prm->spp, prm->bounces);
+    {
+        // The slab test's rounding error is about 2^-22 * (|origin| + |plane|) in position space and the boxes are
+        // padded by 2e-5 * M (M = largest |vertex coordinate|, at least 1): the invariant "results do not depend on
+        // which boxes are visited"  holds for ray origins within about 40 M.  Bounce and shadow
+        // rays start on the mesh; the camera is checked here.
+        const float reach = kCameraReach * (c->pt.bvh_pad / 2e-5f);
+        for (int a = 0; a < 3; a++)
+            if (!(std::fabs(pos[a]) <= reach))
+                return c->fail(RT_ERR_INVALID, "camera position %g is outside +-%g (= %g x the mesh's largest |coordinate|): beyond the range the BVH box padding covers",
+                               (double)pos[a], (double)reach, (double)kCameraReach);
+    }
     if (int rc = bind(c)) return rc;
     PtData& pt = c->pt;
 
@@ -190,8 +213,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     const uint32_t refill_min = (prm->tune_refill_min & 0xffu ? std::min<uint32_t>(prm->tune_refill_min & 0xffu, 64u) : 24u) | (prm->tune_refill_min & 0xff00u);
     const uint32_t grid_stride = (uint32_t)c->n_cus * 2u;  // 1024-thread workgroups, grid-stride
 
-    static thread_local std::vector<hipEvent_t> ev_pool;
-    StageTimer tm{c, c->cfg.profile_stages != 0, ev_pool, {}, 0};
+    StageTimer tm{c, c->cfg.profile_stages != 0, pt.ev_pool, {}, 0};
 
     RT_HIP(c, hipMemsetAsync(pt.d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
@@ -295,6 +317,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         }
     }
     RT_HIP(c, hipEventRecord(c->ev_end, c->stream));
+    if (tm.err != hipSuccess) return c->fail(RT_ERR_HIP, "stage-timing event: %s", hipGetErrorString(tm.err));
     c->frame_valid = true;
     pt.stats.launches_trace_closest = launches_closest;
     pt.stats.launches_trace_shadow = launches_shadow;
@@ -317,7 +340,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         if (tm.on) {
             for (auto& m : tm.marks) {
                 float ms = 0.0f;
-                if (m.second + 1 < tm.used && hipEventElapsedTime(&ms, ev_pool[m.second], ev_pool[m.second + 1]) == hipSuccess) sums[m.first] += ms;
+                if (m.second + 1 < tm.used && hipEventElapsedTime(&ms, pt.ev_pool[m.second], pt.ev_pool[m.second + 1]) == hipSuccess) sums[m.first] += ms;
             }
         }
         pt.stats.ms_generate = sums[0];
@@ -340,6 +363,8 @@ void pt_free(Ctx* c) {
     if (c->pt.ev_shaded) (void)hipEventDestroy(c->pt.ev_shaded);
     if (c->pt.ev_shadowed) (void)hipEventDestroy(c->pt.ev_shadowed);
     c->pt.ev_shaded = c->pt.ev_shadowed = nullptr;
+    for (hipEvent_t e : c->pt.ev_pool) (void)hipEventDestroy(e);
+    c->pt.ev_pool.clear();
 }
 
 // `lane` renders with `owner`'s device mesh (read-only during rendering); the owner tells its lanes
@@ -390,9 +415,10 @@ int rt_default_pt_params(rt_pt_params* p) {
     return RT_OK;
 }
 
-int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const float* emission, uint32_t n_tris) {
-    Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    if (!c) return RT_ERR_INVALID;
+}  // extern "C"
+
+namespace {
+int set_mesh_impl(Ctx* c, const float* verts, const float* albedo, const float* emission, uint32_t n_tris) {
     if (!verts || !albedo || !emission) return c->fail(RT_ERR_INVALID, "mesh arrays must not be NULL");
     if (n_tris == 0 || n_tris >= (1u << 28)) return c->fail(RT_ERR_INVALID, "n_tris %u out of [1, 2^28)", n_tris);
     for (size_t i = 0; i < (size_t)n_tris * 9; i++)
@@ -466,6 +492,31 @@ int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const floa
     pt.stats.n_lights = pt.n_lights;
     pt.stats.bvh_build_ms = pt.bvh_build_ms;
     return RT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const float* emission, uint32_t n_tris) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return RT_ERR_INVALID;
+    // the builder allocates host vectors sized by n_tris and starts std::threads: nothing may leave this
+    // function as a C++ exception (include/rt_abi.h: never throws or aborts across the boundary)
+    try {
+        return set_mesh_impl(c, verts, albedo, emission, n_tris);
+    } catch (const std::bad_alloc&) {
+        free_mesh(c->pt);
+        return c->fail(RT_ERR_OOM, "host memory for a mesh of %u triangles", n_tris);
+    } catch (const std::system_error& e) {
+        free_mesh(c->pt);
+        return c->fail(RT_ERR_STATE, "BVH build: %s", e.what());
+    } catch (const std::exception& e) {
+        free_mesh(c->pt);
+        return c->fail(RT_ERR_INVALID, "BVH build: %s", e.what());
+    } catch (...) {
+        free_mesh(c->pt);
+        return c->fail(RT_ERR_INVALID, "BVH build failed");
+    }
 }
 
 int rt_render_pt(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, float* rgb_out) {

@@ -179,6 +179,7 @@ struct PtData {  // device residency of one mesh + the wavefront buffers
     unsigned long long* d_spill = nullptr;
     size_t spill_words = 0, spill_half = 0;
     hipEvent_t ev_shaded = nullptr, ev_shadowed = nullptr;  // ordering between the main and the auxiliary stream
+    std::vector<hipEvent_t> ev_pool;  // profile_stages: timing events, created on this context's device, freed by pt_free
     // wavefront buffers, sized for cap_paths
     uint64_t cap_paths = 0;
     uint32_t cap_depth = 0;
@@ -210,6 +211,7 @@ struct Ctx {
     uint32_t level_batch = 0;            // images allocated per level
     uint32_t last_image = 0;             // image of the batch that holds the last sample rendered
     float* d_rgb = nullptr;         // full frame, f32 x 3
+    uint8_t* d_rgba8 = nullptr;     // rt_read_rgba8 staging, width*height*4, allocated on first use, freed with the frame
     uint64_t* d_counters = nullptr;  // 1024 slots of hit-pixel counts, summed on the host
     Partition part{0, 1, 0, 0};
 

@@ -379,3 +379,25 @@ def gather_tiles(mine, gathered, rank, dist):
     to rank 0 (torch.distributed gather; backend nccl = RCCL over xGMI on GPUs, gloo in the CPU tests).
     `gathered` is a (world, tiles_per_rank, 64, 64, 3) tensor on rank 0, None elsewhere."""
     dist.gather(mine, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+
+
+def owned_tiles(total_tiles, rank, n_ranks):
+    """Tiles of a frame of `total_tiles` that belong to `rank` (tile t -> rank t % n_ranks); rt_tile_info's `owned`."""
+    return (total_tiles - rank + n_ranks - 1) // n_ranks if total_tiles > rank else 0
+
+
+def gather_owned_tiles(mine, gathered, rank, world, total_tiles, dist):
+    """The exchange as rt_gather_tiles (csrc/rt_abi_comm.hip) does it, with torch.distributed point-to-point
+    calls: every rank sends exactly the tiles it owns, the root receives each peer's own count into that
+    peer's block of `gathered` and copies its own; pad tiles of an uneven split are neither read nor written."""
+    if rank == 0:
+        k0 = owned_tiles(total_tiles, 0, world)
+        gathered[0, :k0] = mine[:k0]
+        for peer in range(1, world):
+            k = owned_tiles(total_tiles, peer, world)
+            if k:
+                dist.recv(gathered[peer, :k], src=peer)
+    else:
+        k = owned_tiles(total_tiles, rank, world)
+        if k:
+            dist.send(mine[:k].contiguous(), dst=0)

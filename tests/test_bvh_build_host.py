@@ -42,3 +42,24 @@ def test_builder_threads_are_race_free_and_deterministic(checker_tsan):
     assert many.returncode == 0 and many.stdout.startswith("OK") and "ThreadSanitizer" not in many.stderr, many.stdout + many.stderr
     one = subprocess.run(["taskset", "-c", "0", checker_tsan, "150000", "11", "0.2"], capture_output=True, text=True)
     assert one.returncode == 0 and one.stdout == many.stdout, one.stdout + one.stderr
+
+
+@pytest.fixture(scope="module")
+def checker_limited(tmp_path_factory):
+    """bvh_check with tests/native/thread_limit.cpp: pthread_create fails with EAGAIN after
+    RT_TEST_THREAD_BUDGET calls (what a thread / process limit of the box looks like to std::thread)."""
+    exe = tmp_path_factory.mktemp("bvh_lim") / "bvh_check"
+    subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "native", "bvh_check.cpp"),
+                    os.path.join(ROOT, "tests", "native", "thread_limit.cpp"), os.path.join(ROOT, "raytracing_engine_amd", "csrc", "bvh_build.cpp"),
+                    "-ldl", "-o", str(exe)], check=True)
+    return str(exe)
+
+
+@pytest.mark.parametrize("budget", [0, 1, 2, 5])
+def test_builder_survives_a_thread_limit(checker_limited, budget):
+    """std::thread construction that throws std::system_error (thread limit) must neither terminate the
+    process nor change the tree: the chunks / subtrees whose thread could not start run on the caller."""
+    free = subprocess.run([checker_limited, "150000", "11", "0.2"], capture_output=True, text=True)
+    assert free.returncode == 0 and free.stdout.startswith("OK"), free.stdout + free.stderr
+    lim = subprocess.run([checker_limited, "150000", "11", "0.2"], capture_output=True, text=True, env=dict(os.environ, RT_TEST_THREAD_BUDGET=str(budget)))
+    assert lim.returncode == 0 and lim.stdout == free.stdout, lim.stdout + lim.stderr

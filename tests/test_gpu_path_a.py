@@ -233,6 +233,13 @@ def test_deterministic_and_rgba8(renderer):
     b = renderer.render()
     assert np.array_equal(a, b)
     assert np.array_equal(rgba, O.to_unorm8(a))
+    # rt_read_rgba8 sits in a per-frame loop: its staging buffer is kept across calls and follows rt_resize
+    for pos in [(0, 1, 0), (1, 0, 0.5)]:
+        c = renderer.render(pos=pos)
+        assert np.array_equal(renderer.read_rgba8(), O.to_unorm8(c))
+    renderer.resize(96, 64)
+    c = renderer.render()
+    assert np.array_equal(renderer.read_rgba8(), O.to_unorm8(c)) and renderer.read_rgba8().shape == (64, 96, 4)
 
 
 @pytest.mark.parametrize("n_ranks", [2, 3, 8])

@@ -238,3 +238,26 @@ def test_queue_streams_cover_every_entry_exactly_once(renderer):
     mesh = scenes.cornell_tri_scene()
     for w, h in [(1, 1), (7, 9), (8, 8), (63, 1), (64, 1), (65, 1), (32, 32), (1023, 1), (1025, 1), (129, 17)]:
         check_pt(renderer, mesh, w, h, pos=(0, 1, 0), spp=1, bounces=2, seed=w * 31 + h)
+
+
+def test_far_camera_within_the_padded_range_and_rejection_beyond(renderer):
+    """The ray/box test's rounding error grows with the distance of the ray origin; the box padding covers
+    camera coordinates up to 32 x the mesh's largest |coordinate| (include/rt_abi.h, rt_render_pt).  A
+    telephoto view from just inside that range must still equal the oracle (whose own BVH and box test are
+    different: any missed box would show); beyond it the call is refused."""
+    mesh = scenes.soup_scene(20000, seed=6, edge=0.8)
+    m = float(np.abs(mesh[0]).max())
+    renderer.set_mesh(*mesh)
+    w, h = 96, 64
+    renderer.resize(w, h, ratio=(0.016, 0.016 * h / w))  # the scene fills the view from ~800 units away
+    pos = (0.0, -31.0 * m, 0.0)
+    rgb = renderer.render_pt(pos=pos, spp=2, bounces=1, seed=3, sky=(0.3, 0.3, 0.4))
+    ref, ct = O.TriScene(*mesh).render(w, h, pos=pos, ratio=(0.016, 0.016 * h / w), spp=2, bounces=1, seed=3, sky=(0.3, 0.3, 0.4))
+    st = renderer.pt_stats()
+    assert ct["bounce_rays"] > 0.5 * ct["camera_rays"], "the view must look at the mesh"
+    assert np.array_equal(rgb, ref)
+    assert (st["camera_rays"], st["bounce_rays"], st["shadow_rays"]) == (ct["camera_rays"], ct["bounce_rays"], ct["shadow_rays"])
+    with pytest.raises(R.RtError) as ei:
+        renderer.render_pt(pos=(0.0, -33.0 * m, 0.0), spp=1)
+    assert ei.value.code == -1 and "padding" in str(ei.value)
+    renderer.resize(64, 64)

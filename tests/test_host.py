@@ -134,19 +134,34 @@ assert float(t) == float(world)
 if rank == 0:
     out = host.tiles_to_frame(gathered.numpy().reshape(-1, 64, 64, 3), world, per, w, h)
     assert np.array_equal(out, frame), "tile-split frame differs from the single-rank frame"
+# the exchange as rt_gather_tiles does it: every rank sends only the tiles it owns (20 tiles on 3 ranks: 7, 7, 6);
+# the tile buffer holds exactly `owned` tiles, as include/rt_abi.h documents, and the pad tile of the short rank
+# stays as the root left it
+owned = host.owned_tiles(tx * ty, rank, world)
+exact = mine[:owned].clone()
+gathered2 = torch.full((world, per, 64, 64, 3), -1.0) if rank == 0 else None
+host.gather_owned_tiles(exact, gathered2, rank, world, tx * ty, dist)
+if rank == 0:
+    out = host.tiles_to_frame(gathered2.numpy().reshape(-1, 64, 64, 3), world, per, w, h)
+    assert np.array_equal(out, frame), "owned-count exchange differs from the single-rank frame"
+    for peer in range(world):
+        k = host.owned_tiles(tx * ty, peer, world)
+        assert (gathered2[peer, k:] == -1.0).all(), "a pad tile was written"
     print("OK")
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
-def test_two_rank_gather_over_gloo(tmp_path):
-    """world_size 2 on CPU: the N>1 path of bench.py (tile ownership, gather to rank 0, de-tile)."""
+@pytest.mark.parametrize("world,port", [(2, 29517), (3, 29519)])
+def test_gather_over_gloo(tmp_path, world, port):
+    """world_size 2 and 3 on CPU: the N>1 path of bench.py (tile ownership, gather to rank 0, de-tile), and the
+    owned-count exchange of rt_gather_tiles on an uneven split (300x200 = 20 tiles on 3 ranks: 7, 7, 6)."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-             for r in range(2)]
+             for r in range(world)]
     outs = [p.communicate(timeout=180) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
