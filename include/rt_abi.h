@@ -262,6 +262,12 @@ int rt_get_pt_stats(rt_ctx* ctx, rt_pt_stats* stats);
  * t_out[i] = distance (inf on miss), tri_out[i] = original triangle index or -1;
  * any_hit = 1: tri_out[i] = 1 if the open segment (o, o + 0.999*d) is occluded. */
 int rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int32_t* tri_out);
+/* Test hook: as rt_trace_rays, and counts_out[2i], counts_out[2i+1] (may be NULL) receive the number of BVH
+ * nodes fetched and triangles tested for ray i by the traversal step functions the render kernels run:
+ * tests/native/bvh8_walk.cpp walks the same tree on the host and must reproduce them exactly, which is what
+ * entitles bench.py to quote rt_pt_stats.nodes_visited / tris_tested. */
+int rt_trace_rays_counted(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int32_t* tri_out,
+                          uint32_t* counts_out);
 
 #ifdef __cplusplus
 }

@@ -125,6 +125,7 @@ PROTOTYPES = {
     "rt_frame_wait": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "rt_frame_poll": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_int)]),
     "rt_trace_rays": (C.c_int, [_vp, _fp, _fp, C.c_uint32, C.c_int, _fp, C.POINTER(C.c_int32)]),
+    "rt_trace_rays_counted": (C.c_int, [_vp, _fp, _fp, C.c_uint32, C.c_int, _fp, C.POINTER(C.c_int32), _u32p]),
 }
 
 _lib = None

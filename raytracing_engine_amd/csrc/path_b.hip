@@ -593,30 +593,41 @@ __global__ __launch_bounds__(256) void pt_resolve(const PtFrame f, PtState st, f
 }
 
 // ---- test hook: trace a batch of caller-supplied rays ---------------------------------------------
+template <bool COUNT>
 __device__ __forceinline__ void trace_one_ray(const PtScene& sc, const float* __restrict__ origins, const float* __restrict__ dirs, uint32_t i,
-                                              int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out, TravStack& stk) {
+                                              int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out, TravStack& stk, TravCounters& tc) {
     const v3 o = mk(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]), d = mk(dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]);
-    TravCounters tc{0, 0, 0};
     if (any_hit) {
         Hit h{kShadowTmax, -1, 0u};
-        const bool occ = traverse<true, false>(sc.nodes, sc.tris, o, d, stk, h, tc);
+        const bool occ = traverse<true, COUNT>(sc.nodes, sc.tris, o, d, stk, h, tc);
         t_out[i] = occ ? 1.0f : 0.0f;
         tri_out[i] = occ ? 1 : 0;
     } else {
         Hit h{__builtin_inff(), -1, 0xffffffffu};
-        traverse<false, false>(sc.nodes, sc.tris, o, d, stk, h, tc);
+        traverse<false, COUNT>(sc.nodes, sc.tris, o, d, stk, h, tc);
         t_out[i] = h.t;
         tri_out[i] = h.li < 0 ? -1 : (int)h.id;
     }
 }
 
+// counts != nullptr: per-ray node fetches and triangle tests (counts[2i], counts[2i+1]) of the very step
+// functions the render kernels run, for the host-side cross-check of the traversal statistics
+template <bool COUNT>
 __global__ __launch_bounds__(256) void pt_trace_rays(const PtScene sc, const float* __restrict__ origins, const float* __restrict__ dirs, uint32_t n,
-                                                     int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out, const StackCfg sk) {
+                                                     int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out, uint32_t* __restrict__ counts,
+                                                     const StackCfg sk) {
     extern __shared__ unsigned long long lds_stack[];
     // grid-stride so the spill columns (one per launched thread) stay within sk.spill_stride
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
     TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
-    for (uint32_t i = (uint32_t)gtid; i < n; i += gridDim.x * 256u) trace_one_ray(sc, origins, dirs, i, any_hit, t_out, tri_out, stk);
+    for (uint32_t i = (uint32_t)gtid; i < n; i += gridDim.x * 256u) {
+        TravCounters tc{0, 0, 0};
+        trace_one_ray<COUNT>(sc, origins, dirs, i, any_hit, t_out, tri_out, stk, tc);
+        if (COUNT) {
+            counts[2 * (size_t)i] = tc.nodes;
+            counts[2 * (size_t)i + 1] = tc.tris;
+        }
+    }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
@@ -657,10 +668,11 @@ int launch_pt_resolve(Ctx* c, const PtFrame& f, const PtState& st, float* acc, f
 }
 
 int launch_pt_trace_rays(Ctx* c, const PtScene& sc, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int* tri_out,
-                         const StackCfg& sk, uint32_t grid) {
+                         uint32_t* counts, const StackCfg& sk, uint32_t grid) {
     if ((size_t)grid * 256u > sk.spill_stride) return c->fail(RT_ERR_INVALID, "bad traversal stack configuration");
-    hipLaunchKernelGGL(pt_trace_rays, dim3(grid), dim3(256), (size_t)sk.lds_cap * 256 * sizeof(unsigned long long), c->stream, sc, origins, dirs, n, any_hit, t_out,
-                       tri_out, sk);
+    const size_t lds = (size_t)sk.lds_cap * 256 * sizeof(unsigned long long);
+    if (counts) hipLaunchKernelGGL(pt_trace_rays<true>, dim3(grid), dim3(256), lds, c->stream, sc, origins, dirs, n, any_hit, t_out, tri_out, counts, sk);
+    else hipLaunchKernelGGL(pt_trace_rays<false>, dim3(grid), dim3(256), lds, c->stream, sc, origins, dirs, n, any_hit, t_out, tri_out, counts, sk);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }

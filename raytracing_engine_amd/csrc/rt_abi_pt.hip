@@ -544,7 +544,8 @@ int rt_get_pt_stats(rt_ctx* ctx, rt_pt_stats* stats) {
     return RT_OK;
 }
 
-int rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int32_t* tri_out) {
+int rt_trace_rays_counted(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int32_t* tri_out,
+                          uint32_t* counts_out) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return RT_ERR_INVALID;
     if (!origins || !dirs || !t_out || !tri_out) return c->fail(RT_ERR_INVALID, "NULL ray buffer");
@@ -553,26 +554,33 @@ int rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t
     if (int rc = bind(c)) return rc;
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
     int* d_i = nullptr;
+    uint32_t* d_c = nullptr;
     const size_t nb = (size_t)n;
     int rc = RT_OK;
-    if (!dalloc(d_o, nb * 3) || !dalloc(d_d, nb * 3) || !dalloc(d_t, nb) || !dalloc(d_i, nb)) rc = c->fail(RT_ERR_OOM, "ray buffers");
+    if (!dalloc(d_o, nb * 3) || !dalloc(d_d, nb * 3) || !dalloc(d_t, nb) || !dalloc(d_i, nb) || (counts_out && !dalloc(d_c, nb * 2))) rc = c->fail(RT_ERR_OOM, "ray buffers");
     hipError_t e = hipSuccess;
     if (!rc) e = hipMemcpy(d_o, origins, nb * 12, hipMemcpyHostToDevice);
     if (!rc && e == hipSuccess) e = hipMemcpy(d_d, dirs, nb * 12, hipMemcpyHostToDevice);
     rt::StackCfg sk{};
     uint32_t grid = 0;
     if (!rc) rc = stack_config(c, 0, 0, (uint64_t)n, &sk, &grid);
-    if (!rc && e == hipSuccess) rc = rt::launch_pt_trace_rays(c, scene_view(c->pt), d_o, d_d, n, any_hit, d_t, d_i, sk, std::min<uint32_t>(grid, (n + 255u) / 256u));
+    if (!rc && e == hipSuccess) rc = rt::launch_pt_trace_rays(c, scene_view(c->pt), d_o, d_d, n, any_hit, d_t, d_i, d_c, sk, std::min<uint32_t>(grid, (n + 255u) / 256u));
     if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (!rc && e == hipSuccess) e = hipMemcpy(t_out, d_t, nb * 4, hipMemcpyDeviceToHost);
     if (!rc && e == hipSuccess) e = hipMemcpy(tri_out, d_i, nb * 4, hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess && counts_out) e = hipMemcpy(counts_out, d_c, nb * 8, hipMemcpyDeviceToHost);
     dfree(d_o);
     dfree(d_d);
     dfree(d_t);
     dfree(d_i);
+    dfree(d_c);
     if (rc) return rc;
     if (e != hipSuccess) return c->fail(RT_ERR_HIP, "rt_trace_rays: %s", hipGetErrorString(e));
     return RT_OK;
+}
+
+int rt_trace_rays(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out, int32_t* tri_out) {
+    return rt_trace_rays_counted(ctx, origins, dirs, n, any_hit, t_out, tri_out, nullptr);
 }
 
 }  // extern "C"

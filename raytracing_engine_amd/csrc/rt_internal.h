@@ -265,7 +265,7 @@ int launch_pt_shade(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& 
                     uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid);
 int launch_pt_resolve(Ctx* c, const PtFrame& f, const PtState& st, float* acc, float* dst, int tile_major);
 int launch_pt_trace_rays(Ctx* c, const PtScene& sc, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out,
-                         int* tri_out, const StackCfg& sk, uint32_t grid);
+                         int* tri_out, uint32_t* counts, const StackCfg& sk, uint32_t grid);
 void pt_free(Ctx* c);
 void comm_free(Ctx* c);  // rt_abi_comm.hip
 

@@ -331,16 +331,19 @@ class Renderer:
         self._check(self._lib.rt_get_pt_stats(self._ctx, C.byref(s)))
         return s.as_dict()
 
-    def trace_rays(self, origins, dirs, any_hit=False):
-        """Test hook: closest hit (t, original triangle index) or occlusion flags for a ray batch."""
+    def trace_rays(self, origins, dirs, any_hit=False, counted=False):
+        """Test hook: closest hit (t, original triangle index) or occlusion flags for a ray batch;
+        counted=True also returns an (n, 2) array of BVH nodes fetched / triangles tested per ray."""
         origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
         dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
         n = len(origins)
         t = np.empty(n, np.float32)
         tri = np.empty(n, np.int32)
-        self._check(self._lib.rt_trace_rays(self._ctx, _fptr(origins), _fptr(dirs), n, int(any_hit), _fptr(t),
-                                            tri.ctypes.data_as(C.POINTER(C.c_int32))))
-        return t, tri
+        counts = np.zeros((n, 2), np.uint32) if counted else None
+        self._check(self._lib.rt_trace_rays_counted(self._ctx, _fptr(origins), _fptr(dirs), n, int(any_hit), _fptr(t),
+                                                    tri.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    counts.ctypes.data_as(C.POINTER(C.c_uint32)) if counted else None))
+        return (t, tri, counts) if counted else (t, tri)
 
 
 def tile_owner(tile_index, n_ranks):

@@ -82,3 +82,8 @@ def test_sketched_variants_and_frames_in_flight(exe, tmp_path):
     res = subprocess.run([exe, "--size", "160x96", "--frames", "5", "--inflight", "3", "--out", str(b)], check=True, capture_output=True, text=True)
     assert "through 3 slots" in res.stdout
     assert np.array_equal(read_ppm(a), read_ppm(b))
+    # and against the oracle: UNORM8 of oracle A's frame (PPM is top-down); one 8-bit step is allowed where
+    # the 1e-4 RGB tolerance straddles a rounding boundary
+    ref8 = O.to_unorm8(O.render_a(O.default_scene(), 160, 96)["rgb"])[::-1, :, :3]
+    diff = np.abs(read_ppm(b).astype(np.int16) - ref8.astype(np.int16))
+    assert diff.max() <= 1 and np.count_nonzero(diff) <= 0.001 * diff.size

@@ -261,3 +261,55 @@ def test_far_camera_within_the_padded_range_and_rejection_beyond(renderer):
         renderer.render_pt(pos=(0.0, -33.0 * m, 0.0), spp=1)
     assert ei.value.code == -1 and "padding" in str(ei.value)
     renderer.resize(64, 64)
+
+
+@pytest.fixture(scope="module")
+def walker(tmp_path_factory):
+    """tests/native/bvh8_walk.cpp: an independent host-side walk of the same compressed 8-wide BVH."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path_factory.mktemp("walk") / "bvh8_walk"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-ffp-contract=off", "-fno-fast-math", os.path.join(root, "tests", "native", "bvh8_walk.cpp"),
+                    os.path.join(root, "raytracing_engine_amd", "csrc", "bvh_build.cpp"), "-o", str(exe)], check=True)
+    return str(exe)
+
+
+@pytest.mark.parametrize("n_tris,edge", [(30000, 0.6), (38, 0.0)])
+def test_traversal_counts_match_the_host_walk_of_the_same_bvh(renderer, walker, tmp_path, n_tris, edge):
+    """bench.py's roofline quotes rt_pt_stats.nodes_visited / tris_tested.  They are produced by the traversal
+    step functions themselves (COUNT instantiation); here an independent host program (scalar per-child code
+    written from the node layout) walks the same tree for the same rays and must report the same number of
+    node fetches and triangle tests for EVERY ray, closest-hit and any-hit, plus the same hits."""
+    import subprocess
+
+    mesh = scenes.cornell_tri_scene() if n_tris == 38 else scenes.soup_scene(n_tris, seed=12, edge=edge)
+    v = mesh[0]
+    renderer.set_mesh(*mesh)
+    rng = np.random.default_rng(3)
+    n = 6000
+    o = rng.uniform([-12, 0, -12], [12, 30, 12], size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    # a coherent camera-like fan from one origin, and axis-parallel rays
+    o[:2000] = (0, 1, 0)
+    fan = np.stack([np.linspace(-0.6, 0.6, 2000), np.ones(2000), 0.4 * np.sin(np.linspace(0, 40, 2000))], 1)
+    d[:2000] = (fan / np.linalg.norm(fan, axis=1, keepdims=True)).astype(np.float32)
+    d[2000:2050] = (0, 1, 0)
+    d[2050:2100] = (-1, 0, 0)
+    for any_hit in (0, 1):
+        dd = (d * rng.uniform(1, 25, size=(n, 1))).astype(np.float32) if any_hit else d
+        t, tri, counts = renderer.trace_rays(o, dd, any_hit=bool(any_hit), counted=True)
+        fin, fout = tmp_path / f"in{any_hit}.bin", tmp_path / f"out{any_hit}.bin"
+        with open(fin, "wb") as f:
+            f.write(np.array([len(v), n, any_hit], np.uint32).tobytes())
+            f.write(np.ascontiguousarray(v, np.float32).tobytes())
+            f.write(o.tobytes())
+            f.write(dd.tobytes())
+        subprocess.run([walker, str(fin), str(fout)], check=True)
+        rec = np.fromfile(fout, dtype=np.dtype([("nodes", "<u4"), ("tris", "<u4"), ("t", "<f4"), ("tri", "<i4")]))
+        assert len(rec) == n
+        assert np.array_equal(rec["tri"], tri) and np.array_equal(rec["t"], t)
+        assert np.array_equal(rec["nodes"], counts[:, 0]), f"node fetches differ for {np.count_nonzero(rec['nodes'] != counts[:, 0])} rays"
+        assert np.array_equal(rec["tris"], counts[:, 1]), f"triangle tests differ for {np.count_nonzero(rec['tris'] != counts[:, 1])} rays"
+        assert counts[:, 0].min() >= 1 and (n_tris == 38 or counts[:, 0].sum() > 3 * n)

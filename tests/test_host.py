@@ -174,3 +174,28 @@ def test_graft_entry_build_runs():
     import __graft_entry__ as g
 
     g.build()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` as a plain command (no torch.distributed.run around it): the parent spawns N rank
+    processes before anything touches a GPU, relays rank 0's JSON line and propagates a rank's failure.  Driven
+    here through the stub step (gloo, no GPU): launcher, RANK / WORLD_SIZE / MASTER_* plumbing, the timed bracket,
+    the max-over-ranks reduction and the tile gather are bench.py's own code."""
+    import json
+
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub-step"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["stub"] is True
+    assert out["parity"]["ok"] and out["config"]["rays_per_step"] == 300 * 200
+    assert out["ms_per_step"] >= 4.0  # the slower rank (2 x 2 ms per step) sets the time: max over ranks
+    bad = subprocess.run([sys.executable, bench, "--gpus", "3", "--steps", "2", "--stub-step", "--stub-fail-rank", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 3 and "rank 2 exited" in bad.stderr
+    assert not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+    # under an external launcher the environment decides; a mismatch is refused
+    mism = subprocess.run([sys.executable, bench, "--gpus", "2", "--stub-step"], env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert mism.returncode != 0 and "WORLD_SIZE=1" in mism.stderr
