@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -227,6 +227,8 @@ typedef struct rt_pt_params {
     uint32_t tune_blocks_per_cu; /* tuning: persistent workgroups per CU (0 = as many as the LDS stacks allow, fewer for few paths) */
     uint32_t tune_lds_stack;     /* tuning: traversal-stack entries kept in LDS per lane (0 = default 8), rest spills */
     uint32_t tune_no_overlap;    /* tuning: 1 = keep the shadow kernel on the main stream (no overlap with the next closest-hit kernel) */
+    uint32_t tune_no_packet;     /* tuning: 1 = camera rays go through the per-lane traversal kernel like every other ray
+                                    (default 0: wave-uniform packet traversal for camera rays) */
 } rt_pt_params;
 
 typedef struct rt_pt_stats {
@@ -235,12 +237,15 @@ typedef struct rt_pt_stats {
     float bvh_build_ms;
     uint32_t stack_overflow;   /* must be 0: traversal stack never exceeded */
     uint64_t camera_rays, bounce_rays, shadow_rays; /* last render: rays handed to BVH traversal */
-    uint64_t nodes_visited, tris_tested;            /* closest-hit launches; last render, count_traversal = 1 only */
+    uint64_t nodes_visited, tris_tested;            /* closest-hit launches: BVH node records fetched / triangle records fetched and tested;
+                                                       last render, count_traversal = 1 only.  The packet kernel fetches a record once per
+                                                       wave (64 camera rays), the per-lane kernel once per ray */
     uint64_t shadow_nodes_visited, shadow_tris_tested; /* any-hit (shadow) launches, same condition */
     uint64_t wave_rounds, alive_lane_rounds;           /* closest-hit launches: traversal rounds per wave summed, lanes holding a live ray summed */
     float ms_total;            /* last render: HIP-event time around the stage loop */
     float ms_generate, ms_trace_closest, ms_shade, ms_trace_shadow, ms_resolve; /* profile_stages = 1 only */
     uint32_t launches_trace_closest, launches_trace_shadow;
+    uint64_t packets;          /* camera-ray waves walked by the packet kernel; last render, count_traversal = 1 only */
 } rt_pt_stats;
 
 int rt_default_pt_params(rt_pt_params* p);

@@ -63,7 +63,8 @@ class Stats(C.Structure):
 class PtParams(C.Structure):  # rt_pt_params
     _fields_ = [("spp", C.c_uint32), ("bounces", C.c_uint32), ("seed", C.c_uint32), ("sky", C.c_float * 3),
                 ("ray_eps", C.c_float), ("count_traversal", C.c_uint32), ("max_paths", C.c_uint32),
-                ("tune_refill_min", C.c_uint32), ("tune_blocks_per_cu", C.c_uint32), ("tune_lds_stack", C.c_uint32), ("tune_no_overlap", C.c_uint32)]
+                ("tune_refill_min", C.c_uint32), ("tune_blocks_per_cu", C.c_uint32), ("tune_lds_stack", C.c_uint32), ("tune_no_overlap", C.c_uint32),
+                ("tune_no_packet", C.c_uint32)]
 
 
 class PtStats(C.Structure):  # rt_pt_stats
@@ -74,7 +75,8 @@ class PtStats(C.Structure):  # rt_pt_stats
                 ("wave_rounds", C.c_uint64), ("alive_lane_rounds", C.c_uint64),
                 ("ms_total", C.c_float), ("ms_generate", C.c_float),
                 ("ms_trace_closest", C.c_float), ("ms_shade", C.c_float), ("ms_trace_shadow", C.c_float),
-                ("ms_resolve", C.c_float), ("launches_trace_closest", C.c_uint32), ("launches_trace_shadow", C.c_uint32)]
+                ("ms_resolve", C.c_float), ("launches_trace_closest", C.c_uint32), ("launches_trace_shadow", C.c_uint32),
+                ("packets", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

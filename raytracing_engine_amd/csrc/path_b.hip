@@ -109,7 +109,8 @@ __device__ __forceinline__ TRay make_tray(v3 o, v3 d, float tmax) {
     r.inv = safe_inv(d);
     r.noi = mk(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
     r.tmax = tmax;
-    r.oct_inv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
+    // by sign BIT, like safe_inv's copysign: a -0.0 component has a negative reciprocal and must take the far plane first
+    r.oct_inv = ((__float_as_uint(d.x) >> 31) ? 0u : 4u) | ((__float_as_uint(d.y) >> 31) ? 0u : 2u) | ((__float_as_uint(d.z) >> 31) ? 0u : 1u);
     return r;
 }
 
@@ -202,7 +203,10 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, cons
         pos4[w] = (m4 ^ (oct4 & (inner4 * 0xffu))) & 0x1f1f1f1fu;
         bits4[w] = (m4 >> 5) & 0x07070707u;
     }
-    const float tlim = r.tmax * 1.0000004f;
+    // No relative slack on the comparison: the build pads every box by 2e-5 * M (M = largest |coordinate|), at least five
+    // times the rounding error of these fmas for ray origins within 32 M (render_pt_common checks the camera), so a box
+    // that holds the ray's hit - or a (t, id) tie - always passes tn <= tf and tn <= tmax.
+    const float tlim = r.tmax;
     uint32_t hitmask = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -211,7 +215,7 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, cons
         const float tny = __builtin_fmaf(ubyte_f32(ny[w], bsel), ay, by), tfy = __builtin_fmaf(ubyte_f32(fy[w], bsel), ay, by);
         const float tnz = __builtin_fmaf(ubyte_f32(nz[w], bsel), az, bz), tfz = __builtin_fmaf(ubyte_f32(fz[w], bsel), az, bz);
         const float tn = fmax_(fmax_(tnx, tny), fmax_(tnz, 0.0f));
-        const float tf = fmin_(fmin_(tfx, tfy), fmin_(tfz, tlim)) * 1.0000004f;
+        const float tf = fmin_(fmin_(tfx, tfy), fmin_(tfz, tlim));
         const uint32_t bits = (bits4[w] >> (8 * bsel)) & 0xffu, pos = (pos4[w] >> (8 * bsel)) & 0xffu;
         if (tn <= tf) hitmask |= bits << pos;
     }
@@ -471,6 +475,147 @@ __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st,
     if (tc.overflow) atomicOr((unsigned int*)&stats[2], 1u);
 }
 
+// ---- packet trace (camera rays) ---------------------------------------------------------------------
+// Camera rays share their origin and the 64 paths of a wave cover a 4x4-pixel block (Morton slots), so the
+// whole wave walks the tree TOGETHER: one wave-uniform traversal (stack of node groups in LDS, node header and
+// triangle records through scalar loads), the 48 quantised planes of a node decoded ONCE per wave - lane k
+// converts plane k and parks it in LDS, ordered near / far for the packet's direction octant - and every
+// lane then only runs the six slab fmas per child against planes broadcast from LDS.  A child is entered
+// when ANY lane's ray hits its box, a leaf's triangles are tested by all lanes (testing more boxes or
+// triangles than a ray needs never changes its (t, id)-minimal hit).  Per node step
+// this costs about 100 vector instructions and one 48-byte vector load for 64 rays, against about 300
+// instructions and 64 x 5 sixteen-byte gathers in pt_trace.  Lanes whose octant differs from the packet
+// leader's (blocks that straddle a sign change of the direction) are walked in a further pass.
+constexpr int kPkStack = 40;  // >= kBvhMaxDepth + 2 groups: one pending sibling group per tree level
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const PtFrame f, PtState st, unsigned long long* __restrict__ stats) {
+    __shared__ float s_planes[4][64];
+    __shared__ unsigned long long s_stack[4][kPkStack];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    float* planes = s_planes[wv];
+    unsigned long long* stack = s_stack[wv];
+    const uint32_t pid = (blockIdx.x * 4u + wv) * 64u + lane;
+
+    bool alive = false;
+    v3 d = mk(0.0f, 1.0f, 0.0f);
+    if (pid < f.n_paths) {
+        uint32_t px, py, lx, ly, k;
+        alive = slot_pixel(f, pid / f.spp_batch, px, py, lx, ly, k);
+        if (alive) {
+            const float4 rd = st.ray_d[pid];
+            d = mk(rd.x, rd.y, rd.z);
+        }
+    }
+    const v3 o = mk(f.cam.pos[0], f.cam.pos[1], f.cam.pos[2]);  // wave-uniform
+    const v3 inv = safe_inv(d);
+    const v3 noi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+    const uint32_t oct_inv = ((__float_as_uint(d.x) >> 31) ? 0u : 4u) | ((__float_as_uint(d.y) >> 31) ? 0u : 2u) | ((__float_as_uint(d.z) >> 31) ? 0u : 1u);
+    Hit best{__builtin_inff(), -1, 0xffffffffu};
+
+    // lane k < 48 decodes plane k of a node: byte 32 + k = qlo.x[8] qlo.y[8] qlo.z[8] qhi.x[8] qhi.y[8] qhi.z[8]
+    const uint32_t pl = lane < 48u ? lane : 47u;
+    const uint32_t p_axis = (pl >> 3) % 3u, p_child = pl & 7u;
+    const bool p_hi = pl >= 24u;
+    uint32_t n_nodes = 0, n_tris = 0, overflow = 0;  // wave-uniform
+
+    unsigned long long remaining = __ballot(alive);
+    while (remaining) {
+        const uint32_t oct = (uint32_t)__builtin_amdgcn_readlane((int)oct_inv, (int)__builtin_ctzll(remaining));
+        const bool act = alive && oct_inv == oct;
+        const unsigned long long act_mask = __ballot(act);  // wave-uniform
+        remaining &= ~act_mask;
+        // LDS slot of this lane's plane: child * 8 + {near x, near y, near z, far x, far y, far z}
+        const bool dir_pos = ((oct >> (2u - p_axis)) & 1u) != 0u;  // oct bit 4 = x, 2 = y, 1 = z: direction >= 0
+        const uint32_t lds_idx = p_child * 8u + (p_hi == dir_pos ? 3u : 0u) + p_axis;
+
+        int sp = 0;
+        uint32_t gx = 0u, gy = 0x80000000u;  // the root group
+        for (;;) {
+            if (gy <= 0x00ffffffu) {
+                if (sp == 0) break;
+                const unsigned long long e = stack[--sp];
+                gx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)e);
+                gy = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(e >> 32));
+            }
+            const uint32_t bit = 31u - (uint32_t)__builtin_clz(gy);
+            const uint32_t hits = gy;
+            gy &= ~(1u << bit);
+            if (gy > 0x00ffffffu) {  // remaining siblings
+                if (sp < kPkStack) {
+                    if (lane == 0) stack[sp] = ((unsigned long long)gy << 32) | gx;
+                    sp++;
+                } else {
+                    overflow = 1;
+                }
+            }
+            const uint32_t slot = (bit - 24u) ^ oct;
+            const uint32_t node = gx + (uint32_t)__builtin_popcount(hits & ~(0xffffffffu << slot));
+            const uint32_t* __restrict__ nd = reinterpret_cast<const uint32_t*>(sc.nodes) + (size_t)node * 20u;
+            if (COUNT) n_nodes++;
+            // header: wave-uniform address -> scalar loads
+            const float px_ = __uint_as_float(nd[0]), py_ = __uint_as_float(nd[1]), pz_ = __uint_as_float(nd[2]);
+            const uint32_t w3 = nd[3], child_base = nd[4], tri_base = nd[5], m_lo = nd[6], m_hi = nd[7];
+            const float sx = __uint_as_float((w3 & 0xffu) << 23), sy = __uint_as_float(((w3 >> 8) & 0xffu) << 23), sz = __uint_as_float(((w3 >> 16) & 0xffu) << 23);
+            const uint32_t imask = w3 >> 24;
+            // cooperative decode: one 48-byte vector load for the wave, world-space plane = p + q * scale
+            const uint32_t q = reinterpret_cast<const uint8_t*>(nd)[32u + pl];
+            const float ps = p_axis == 0u ? sx : p_axis == 1u ? sy : sz, pp = p_axis == 0u ? px_ : p_axis == 1u ? py_ : pz_;
+            const float plane = __builtin_fmaf((float)q, ps, pp);
+            __builtin_amdgcn_wave_barrier();  // the previous node's plane reads are done (one wave: DS ops run in order)
+            if (lane < 48u) planes[lds_idx] = plane;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t any = 0;  // bit c: some ray of the pass hits child slot c (empty slots hold inverted boxes and never hit)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const float4 a = *reinterpret_cast<const float4*>(&planes[c * 8]);      // near x, y, z, far x
+                const float2 b = *reinterpret_cast<const float2*>(&planes[c * 8 + 4]);  // far y, z
+                const float tn = fmax_(fmax_(__builtin_fmaf(a.x, inv.x, noi.x), __builtin_fmaf(a.y, inv.y, noi.y)), fmax_(__builtin_fmaf(a.z, inv.z, noi.z), 0.0f));
+                const float tf = fmin_(fmin_(__builtin_fmaf(a.w, inv.x, noi.x), __builtin_fmaf(b.x, inv.y, noi.y)), fmin_(__builtin_fmaf(b.y, inv.z, noi.z), best.t));
+                any |= (__builtin_amdgcn_ballot_w64(tn <= tf) & act_mask) ? (1u << c) : 0u;
+            }
+            // wave-uniform bookkeeping, branch-free on the scalar unit: inner children to enter, keyed by
+            // slot ^ octant (front to back), and the triangles of the leaf children that were hit
+            uint32_t ih = any & imask;
+            ih = (oct & 1u) ? (((ih & 0x55u) << 1) | ((ih >> 1) & 0x55u)) : ih;
+            ih = (oct & 2u) ? (((ih & 0x33u) << 2) | ((ih >> 2) & 0x33u)) : ih;
+            ih = (oct & 4u) ? (((ih & 0x0fu) << 4) | ((ih >> 4) & 0x0fu)) : ih;
+            const uint32_t inner_hits = ih << 24;
+            uint32_t tri_mask = 0;
+            for (uint32_t lh = any & ~imask; lh; lh &= lh - 1u) {
+                const uint32_t c = (uint32_t)__builtin_ctz(lh);
+                const uint32_t m = ((c < 4u ? m_lo : m_hi) >> (8u * (c & 3u))) & 0xffu;
+                tri_mask |= (m >> 5) << (m & 0x1fu);
+            }
+            while (tri_mask) {
+                const uint32_t tb = (uint32_t)__builtin_ctz(tri_mask);
+                tri_mask &= tri_mask - 1u;
+                const uint32_t li = tri_base + tb;
+                const float* __restrict__ tp = reinterpret_cast<const float*>(sc.tris) + (size_t)li * 12u;  // wave-uniform: scalar loads
+                if (COUNT) n_tris++;
+                float t;
+                if (act && tri_test(o, d, mk(tp[0], tp[1], tp[2]), mk(tp[3], tp[4], tp[5]), mk(tp[6], tp[7], tp[8]), t) && t > 0.0f) {
+                    const uint32_t id = __float_as_uint(tp[9]);
+                    if (t < best.t || (t == best.t && id < best.id)) {
+                        best.t = t;
+                        best.li = (int)li;
+                        best.id = id;
+                    }
+                }
+            }
+            gx = child_base;
+            gy = inner_hits | imask;
+        }
+    }
+    if (alive) st.hit[pid] = make_float2(best.t, __int_as_float(best.li));
+    if (COUNT && lane == 0) {
+        atomicAdd(&stats[0], (unsigned long long)n_nodes);
+        atomicAdd(&stats[1], (unsigned long long)n_tris);
+        atomicAdd(&stats[8], 1ull);
+    }
+    if (overflow && lane == 0) atomicOr((unsigned int*)&stats[2], 1u);
+}
+
 // ---- shade ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, const PtFrame f, PtState st, const uint32_t* __restrict__ queue,
                                                            const uint32_t* __restrict__ count_ptr, uint32_t depth, uint32_t* __restrict__ next_queue,
@@ -650,6 +795,14 @@ int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t
         if (count) hipLaunchKernelGGL((pt_trace<false, true>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
         else hipLaunchKernelGGL((pt_trace<false, false>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
     }
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count) {
+    const dim3 g((f.n_paths + 255u) / 256u), b(256);
+    if (count) hipLaunchKernelGGL(pt_trace_packet<true>, g, b, 0, c->stream, sc, f, st, stats);
+    else hipLaunchKernelGGL(pt_trace_packet<false>, g, b, 0, c->stream, sc, f, st, stats);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }

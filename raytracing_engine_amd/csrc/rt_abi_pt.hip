@@ -20,6 +20,7 @@ namespace {
 
 constexpr uint64_t kMaxPathsInFlight = 1ull << 25;  // 33.5 M paths = 4.3 GB of wavefront state
 constexpr uint32_t kMaxBounces = 15;
+constexpr size_t kStatWords = 16;  // device-side traversal statistics (path_b.hip)
 constexpr float kCameraReach = 32.0f;  // camera |coordinate| limit in units of the mesh's largest |coordinate| (render_pt_common)
 
 int bind(Ctx* c) {
@@ -73,7 +74,7 @@ bool dalloc(T*& p, size_t count) {
 int ensure_wavefront(Ctx* c, uint64_t n_paths, uint64_t n_slots) {
     PtData& pt = c->pt;
     if (!pt.d_ctr) {
-        if (!dalloc(pt.d_ctr, (size_t)rt::PT_CTR_STRIDE * (kMaxBounces + 3)) || !dalloc(pt.d_stats, 8)) return c->fail(RT_ERR_OOM, "path-tracer counters");
+        if (!dalloc(pt.d_ctr, (size_t)rt::PT_CTR_STRIDE * (kMaxBounces + 3)) || !dalloc(pt.d_stats, kStatWords)) return c->fail(RT_ERR_OOM, "path-tracer counters");
     }
     if (n_paths > pt.cap_paths || n_slots > pt.cap_slots) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -215,7 +216,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
 
     StageTimer tm{c, c->cfg.profile_stages != 0, pt.ev_pool, {}, 0};
 
-    RT_HIP(c, hipMemsetAsync(pt.d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipMemsetAsync(pt.d_stats, 0, kStatWords * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     uint64_t cam = 0, bnc = 0, shd = 0;
     uint32_t launches_closest = 0, launches_shadow = 0;
@@ -263,7 +264,9 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             const uint32_t* q = pt.d_queue[d & 1];
             uint32_t* qn = pt.d_queue[(d + 1) & 1];
             tm.begin(1);
-            if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent, stack_cap, refill_min)) return rc;
+            if (d == 0 && !prm->tune_no_packet) {  // camera rays: one shared origin, coherent 4x4-pixel blocks per wave
+                if (int rc = rt::launch_pt_trace_packet(c, sc, f, pt.st, pt.d_stats, count)) return rc;
+            } else if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent, stack_cap, refill_min)) return rc;
             tm.end();
             launches_closest++;
             if (shadow_pending) {  // shade(d) adds sky/emission after shadow(d-1)'s contribution
@@ -323,7 +326,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     pt.stats.launches_trace_shadow = launches_shadow;
     if (sync) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
-        unsigned long long st[8] = {};
+        unsigned long long st[kStatWords] = {};
         RT_HIP(c, hipMemcpy(st, pt.d_stats, sizeof st, hipMemcpyDeviceToHost));
         pt.stats.camera_rays = cam;
         pt.stats.bounce_rays = bnc;
@@ -334,6 +337,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         pt.stats.shadow_tris_tested = st[5];
         pt.stats.wave_rounds = st[6];
         pt.stats.alive_lane_rounds = st[7];
+        pt.stats.packets = st[8];
         pt.stats.stack_overflow = (uint32_t)st[2];
         RT_HIP(c, hipEventElapsedTime(&pt.stats.ms_total, c->ev_begin, c->ev_end));
         float sums[5] = {};
@@ -412,6 +416,7 @@ int rt_default_pt_params(rt_pt_params* p) {
     p->tune_blocks_per_cu = 0;
     p->tune_lds_stack = 0;
     p->tune_no_overlap = 0;
+    p->tune_no_packet = 0;
     return RT_OK;
 }
 

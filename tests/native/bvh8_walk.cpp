@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
         const V3 o = {org[3 * r], org[3 * r + 1], org[3 * r + 2]}, d = {dir[3 * r], dir[3 * r + 1], dir[3 * r + 2]};
         const V3 inv = {1.0f / safe(d.x), 1.0f / safe(d.y), 1.0f / safe(d.z)};
         const V3 noi = {-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)};
-        const bool pos[3] = {!(d.x < 0.0f), !(d.y < 0.0f), !(d.z < 0.0f)};
+        const bool pos[3] = {!std::signbit(d.x), !std::signbit(d.y), !std::signbit(d.z)};  // by sign bit: 1 / -0.0 is negative
         const uint32_t oct_inv = (pos[0] ? 4u : 0u) | (pos[1] ? 2u : 0u) | (pos[2] ? 1u : 0u);  // 7 - octant
         float tmax = any_hit ? kShadowTmax : INFINITY;
         float best_t = INFINITY;
@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
                 a_[a] = s[a] * iv[a];
                 b_[a] = fmaf(p[a], iv[a], nv[a]);
             }
-            const float tlim = tmax * 1.0000004f;
+            const float tlim = tmax;  // the box padding is the slack (see node_step in csrc/path_b.hip)
             uint32_t inner_hit = 0;   // bit (slot ^ oct_inv): inner child in `slot` was hit
             uint32_t tri_bits = 0;    // bit k: leaf triangle tri_base + k is to be tested
             for (int slot = 0; slot < 8; slot++) {
@@ -130,7 +130,6 @@ int main(int argc, char** argv) {
                     tn = std::fmax(tn, t_near);
                     tf = std::fmin(tf, t_far);
                 }
-                tf *= 1.0000004f;
                 if (!(tn <= tf)) continue;
                 if ((m >> 5) == 1u && (m & 0x1fu) >= 24u) inner_hit |= 1u << ((uint32_t)slot ^ oct_inv);  // inner: 001sssss, sssss = 24 + slot
                 else tri_bits |= (m >> 5) << (m & 0x1fu);                                              // leaf: unary count << offset

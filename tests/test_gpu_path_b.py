@@ -45,6 +45,8 @@ def test_trace_rays_matches_bruteforce_oracle(renderer):
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     d[:50] = [0, 1, 0]  # axis-aligned rays (zero direction components)
     d[50:100] = [1, 0, 0]
+    d[100:150] = [-0.0, 1, -0.0]  # negative zeros
+    d[150:200] = [-0.0, -0.0, -1]
     t, tri = renderer.trace_rays(o, d)
     hits = 0
     for i in range(n):
@@ -297,6 +299,8 @@ def test_traversal_counts_match_the_host_walk_of_the_same_bvh(renderer, walker, 
     d[:2000] = (fan / np.linalg.norm(fan, axis=1, keepdims=True)).astype(np.float32)
     d[2000:2050] = (0, 1, 0)
     d[2050:2100] = (-1, 0, 0)
+    d[2100:2150] = (-0.0, 1, -0.0)  # negative zeros: the reciprocal is negative, the octant must follow the sign bit
+    d[2150:2200] = (-0.0, -0.0, 1)
     for any_hit in (0, 1):
         dd = (d * rng.uniform(1, 25, size=(n, 1))).astype(np.float32) if any_hit else d
         t, tri, counts = renderer.trace_rays(o, dd, any_hit=bool(any_hit), counted=True)
