@@ -226,9 +226,13 @@ typedef struct rt_pt_params {
     uint32_t tune_refill_min;    /* tuning: idle lanes per wave that trigger a refill (0 = default 24; byte 1: triangle tests per round, 0 = 1) */
     uint32_t tune_blocks_per_cu; /* tuning: persistent workgroups per CU (0 = as many as the LDS stacks allow, fewer for few paths) */
     uint32_t tune_lds_stack;     /* tuning: traversal-stack entries kept in LDS per lane (0 = default 8), rest spills */
-    uint32_t tune_no_overlap;    /* tuning: 1 = keep the shadow kernel on the main stream (no overlap with the next closest-hit kernel) */
+    uint32_t tune_no_overlap;    /* tuning: how the shadow rays of depth d and the closest-hit rays of depth d + 1 (independent work) share the
+                                    GPU: 0 (default) one persistent launch pulls from both queues; 1 one launch after the other;
+                                    2 two launches on two streams */
     uint32_t tune_no_packet;     /* tuning: 1 = camera rays go through the per-lane traversal kernel like every other ray
                                     (default 0: wave-uniform packet traversal for camera rays) */
+    uint32_t tune_sort_rays;     /* tuning: 1 = bounce and shadow rays are sorted inside each 1024-ray workgroup of the shade stage
+                                    (LDS counting sort on direction octant + origin cell) before they enter the queues */
 } rt_pt_params;
 
 typedef struct rt_pt_stats {

@@ -64,7 +64,7 @@ class PtParams(C.Structure):  # rt_pt_params
     _fields_ = [("spp", C.c_uint32), ("bounces", C.c_uint32), ("seed", C.c_uint32), ("sky", C.c_float * 3),
                 ("ray_eps", C.c_float), ("count_traversal", C.c_uint32), ("max_paths", C.c_uint32),
                 ("tune_refill_min", C.c_uint32), ("tune_blocks_per_cu", C.c_uint32), ("tune_lds_stack", C.c_uint32), ("tune_no_overlap", C.c_uint32),
-                ("tune_no_packet", C.c_uint32)]
+                ("tune_no_packet", C.c_uint32), ("tune_sort_rays", C.c_uint32)]
 
 
 class PtStats(C.Structure):  # rt_pt_stats

@@ -194,13 +194,16 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, cons
     const uint32_t nz[2] = {pz ? lz[0] : hz[0], pz ? lz[1] : hz[1]}, fz[2] = {pz ? hz[0] : lz[0], pz ? hz[1] : lz[1]};
     // per-slot hit-mask fields, four slots per word: inner children (low 5 meta bits in 24..31) get
     // bit 24 + (slot ^ oct_inv), leaves their unary triangle-count mask at their triangle offset
-    const uint32_t oct4 = r.oct_inv * 0x01010101u;
+    const uint32_t oct4 = __builtin_amdgcn_perm(0u, r.oct_inv, 0x00000000u);  // the octant byte in all four bytes (v_perm_b32, no multiply)
     uint32_t bits4[2], pos4[2];
 #pragma unroll
     for (int w = 0; w < 2; w++) {
         const uint32_t m4 = __float_as_uint(w ? n1.w : n1.z);
         const uint32_t inner4 = ((m4 & (m4 << 1)) & 0x10101010u) >> 4;  // 0x01 per inner slot
-        pos4[w] = (m4 ^ (oct4 & (inner4 * 0xffu))) & 0x1f1f1f1fu;
+        uint32_t inner7 = inner4 | (inner4 << 1);  // 0x07 per inner slot: the three slot bits the octant flips
+        __asm__ volatile("" : "+v"(inner7));     // (keeps the compiler from folding the two steps into a quarter-rate v_mul_lo_u32 by 7)
+        inner7 |= inner4 << 2;
+        pos4[w] = (m4 ^ (oct4 & inner7)) & 0x1f1f1f1fu;
         bits4[w] = (m4 >> 5) & 0x07070707u;
     }
     // No relative slack on the comparison: the build pads every box by 2e-5 * M (M = largest |coordinate|), at least five
@@ -318,6 +321,65 @@ __device__ __forceinline__ uint32_t block_append(bool want, uint32_t* counter, u
     return idx;
 }
 
+// Queue append with a sort inside the workgroup ("rays compacted and sorted in LDS"): the rays a workgroup
+// emits are reserved as one contiguous range (one atomic, as block_append) and placed inside it in key
+// order by an LDS counting sort (histogram with returning LDS atomics -> rank in bin, exclusive scan over
+// the bins, position = bin start + rank).  key < kSortBins; the order inside a bin is arrival order (not
+// deterministic, and irrelevant: the queue order never changes a result).  Rays that
+// sit next to each other in the queue are picked up by the same wave of pt_trace.
+// Must be called by every thread of the workgroup.  lds: kSortBins + 40 words.
+constexpr uint32_t kSortBins = 512;
+__device__ __forceinline__ uint32_t block_append_sorted(bool want, uint32_t key, uint32_t* counter, uint32_t* lds) {
+    uint32_t* hist = lds;               // kSortBins
+    uint32_t* wsum = lds + kSortBins;   // 16 wave sums of the scan + 1 base
+    for (uint32_t i = threadIdx.x; i < kSortBins; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    uint32_t rank = 0;
+    if (want) rank = atomicAdd(&hist[key], 1u);
+    __syncthreads();
+    // exclusive scan of the kSortBins counts by the first kSortBins threads (wave scan + wave sums)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t v = 0, incl = 0;
+    if (threadIdx.x < kSortBins) {
+        v = hist[threadIdx.x];
+        incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < kSortBins / 64; w++) {
+            const uint32_t c = wsum[w];
+            wsum[w] = total;
+            total += c;
+        }
+        wsum[16] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSortBins) hist[threadIdx.x] = wsum[wave] + incl - v;  // bin start inside the workgroup's range
+    __syncthreads();
+    const uint32_t idx = want ? wsum[16] + hist[key] + rank : 0u;
+    __syncthreads();  // lds is reused by the next append
+    return idx;
+}
+
+// Sort key of a ray: direction octant (3 bits, major) and the cell of its origin in a 4 x 4 x 4 grid over the
+// BVH root's quantisation frame (6 bits).
+__device__ __forceinline__ uint32_t ray_sort_key(const float4* __restrict__ nodes, v3 o, v3 d) {
+    const float4 n0 = nodes[0];  // root: p.xyz, exponent bytes
+    const uint32_t w3 = __float_as_uint(n0.w);
+    const float ex = __uint_as_float((((w3 & 0xffu) + 6u) & 0xffu) << 23), ey = __uint_as_float(((((w3 >> 8) & 0xffu) + 6u) & 0xffu) << 23),
+                ez = __uint_as_float(((((w3 >> 16) & 0xffu) + 6u) & 0xffu) << 23);  // 64 quantisation steps = a quarter of the frame
+    const int cx = (int)((o.x - n0.x) / ex), cy = (int)((o.y - n0.y) / ey), cz = (int)((o.z - n0.z) / ez);
+    const uint32_t ux = (uint32_t)(cx < 0 ? 0 : cx > 3 ? 3 : cx), uy = (uint32_t)(cy < 0 ? 0 : cy > 3 ? 3 : cy), uz = (uint32_t)(cz < 0 ? 0 : cz > 3 ? 3 : cz);
+    const uint32_t oct = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+    return (oct << 6) | (uz << 4) | (uy << 2) | ux;
+}
+
 // ---- generate -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, PtState st, uint32_t* __restrict__ queue, uint32_t* __restrict__ ctr) {
     __shared__ uint32_t lds[32];
@@ -355,12 +417,9 @@ __global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, P
 constexpr int kTrisPerRound = 1;
 
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
-                                                const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
-                                                unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min) {
-    extern __shared__ unsigned long long lds_stack[];  // sk.lds_cap x 256 entries
-    const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
-    TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
+__device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st, const uint32_t* __restrict__ queue,
+                                            const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
+                                            unsigned long long* __restrict__ stats, TravStack& stk, uint32_t refill_min) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t n = *count_ptr;
@@ -473,6 +532,32 @@ __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st,
         }
     }
     if (tc.overflow) atomicOr((unsigned int*)&stats[2], 1u);
+}
+
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
+                                                const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
+                                                unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min) {
+    extern __shared__ unsigned long long lds_stack[];  // sk.lds_cap x 256 entries
+    const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
+    TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
+    trace_queue<ANY, COUNT>(sc, st, queue, count_ptr, head, stats, stk, refill_min);
+}
+
+// closest-hit rays of depth d + 1 and the shadow rays of depth d in ONE persistent launch: the two are independent (the
+// shadow rays only add to the paths' radiance, the closest-hit rays only read rays), so every wave first pulls from the
+// closest-hit queue - the frame's critical path: shade(d + 1) waits for it - and moves on to the shadow queue when that one
+// is dry, instead of leaving the machine to the few long rays of a launch's tail.  One tail per bounce instead of two.
+template <bool COUNT>
+__global__ __launch_bounds__(256, 8) void pt_trace_fused(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
+                                                      const uint32_t* __restrict__ closest_count, uint32_t* __restrict__ closest_head,
+                                                      const uint32_t* __restrict__ shadow_count, uint32_t* __restrict__ shadow_head,
+                                                      unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min) {
+    extern __shared__ unsigned long long lds_stack[];
+    const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
+    TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
+    trace_queue<false, COUNT>(sc, st, queue, closest_count, closest_head, stats, stk, refill_min);
+    trace_queue<true, COUNT>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, refill_min);
 }
 
 // ---- packet trace (camera rays) ---------------------------------------------------------------------
@@ -619,8 +704,8 @@ __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const P
 // ---- shade ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, const PtFrame f, PtState st, const uint32_t* __restrict__ queue,
                                                            const uint32_t* __restrict__ count_ptr, uint32_t depth, uint32_t* __restrict__ next_queue,
-                                                           uint32_t* __restrict__ next_ctr) {
-    __shared__ uint32_t lds[32];
+                                                           uint32_t* __restrict__ next_ctr, uint32_t sort_rays) {
+    __shared__ uint32_t lds[kSortBins + 40];
     const uint32_t n = *count_ptr;
     const uint32_t stride = gridDim.x * kAppendThreads;
     // grid-stride over whole workgroups: the trip count is workgroup-uniform (barriers in block_append)
@@ -695,9 +780,21 @@ __global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, con
                 }
             }
         }
-        const uint32_t bi = block_append(bounce, &next_ctr[PT_CTR_COUNT], lds);
+        uint32_t bi, si;
+        if (sort_rays) {  // wave-uniform
+            uint32_t kb = 0, ks = 0;
+            if (bounce) {
+                const float4 ro = st.ray_o[pid], rd = st.ray_d[pid];
+                kb = ray_sort_key(sc.nodes, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z));
+            }
+            if (shadow) ks = ray_sort_key(sc.nodes, mk(so.x, so.y, so.z), mk(sd.x, sd.y, sd.z));
+            bi = block_append_sorted(bounce, kb, &next_ctr[PT_CTR_COUNT], lds);
+            si = block_append_sorted(shadow, ks, &next_ctr[PT_CTR_SHADOW_COUNT], lds);
+        } else {
+            bi = block_append(bounce, &next_ctr[PT_CTR_COUNT], lds);
+            si = block_append(shadow, &next_ctr[PT_CTR_SHADOW_COUNT], lds);
+        }
         if (bounce) next_queue[bi] = pid;
-        const uint32_t si = block_append(shadow, &next_ctr[PT_CTR_SHADOW_COUNT], lds);
         if (shadow) {
             st.sh_o[si] = so;
             st.sh_d[si] = sd;
@@ -799,6 +896,18 @@ int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t
     return RT_OK;
 }
 
+int launch_pt_trace_fused(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t* queue, const uint32_t* closest_count, uint32_t* closest_head,
+                          const uint32_t* shadow_count, uint32_t* shadow_head, unsigned long long* stats, bool count, uint32_t grid,
+                          const StackCfg& stack_cap, uint32_t refill_min) {
+    if (stack_cap.lds_cap < 1 || stack_cap.lds_cap > 160 || (size_t)grid * 256u > stack_cap.spill_stride)
+        return c->fail(RT_ERR_INVALID, "bad traversal stack configuration");
+    const size_t lds = (size_t)stack_cap.lds_cap * 256 * sizeof(unsigned long long);
+    if (count) hipLaunchKernelGGL(pt_trace_fused<true>, dim3(grid), dim3(256), lds, c->stream, sc, st, queue, closest_count, closest_head, shadow_count, shadow_head, stats, stack_cap, refill_min);
+    else hipLaunchKernelGGL(pt_trace_fused<false>, dim3(grid), dim3(256), lds, c->stream, sc, st, queue, closest_count, closest_head, shadow_count, shadow_head, stats, stack_cap, refill_min);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
 int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count) {
     const dim3 g((f.n_paths + 255u) / 256u), b(256);
     if (count) hipLaunchKernelGGL(pt_trace_packet<true>, g, b, 0, c->stream, sc, f, st, stats);
@@ -808,8 +917,9 @@ int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const Pt
 }
 
 int launch_pt_shade(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr,
-                    uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid) {
-    hipLaunchKernelGGL(pt_shade, dim3(grid), dim3(kAppendThreads), 0, c->stream, sc, f, st, queue, count_ptr, depth, next_queue, next_ctr);
+                    uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid, bool sort_rays) {
+    hipLaunchKernelGGL(pt_shade, dim3(grid), dim3(kAppendThreads), 0, c->stream, sc, f, st, queue, count_ptr, depth, next_queue, next_ctr,
+                       (uint32_t)(sort_rays ? 1 : 0));
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }

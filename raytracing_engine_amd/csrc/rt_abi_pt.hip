@@ -220,12 +220,15 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     uint64_t cam = 0, bnc = 0, shd = 0;
     uint32_t launches_closest = 0, launches_shadow = 0;
-    // per-stage timing needs the stages back to back on one stream
-    // the auxiliary stream exists from the first path-B frame that wants it: streams are dealt onto a few
-    // hardware queues in creation order, and a context that only renders path A should not occupy two
-    const bool want_overlap = !tm.on && !prm->tune_no_overlap && pt.n_lights != 0;
-    if (want_overlap && !c->aux_stream) RT_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-    const bool overlap = want_overlap && c->aux_stream != nullptr;
+    // How shadow(d) and closest(d + 1) share the machine (they are independent: the shadow rays only add to the paths'
+    // radiance, the closest-hit rays only read rays):  0 (default) one persistent launch pulls from both queues
+    // (pt_trace_fused);  2 two launches on two streams (the auxiliary stream exists from the first frame that wants it:
+    // streams are dealt onto a few hardware queues in creation order, and a context that only renders path A should
+    // not occupy two);  1, and always under per-stage timing, one launch after the other on one stream.
+    const uint32_t overlap_mode = (tm.on || pt.n_lights == 0) ? 1u : prm->tune_no_overlap;
+    const bool fused = overlap_mode == 0u;
+    if (overlap_mode == 2u && !c->aux_stream) RT_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    const bool overlap = overlap_mode == 2u && c->aux_stream != nullptr;
     bool shadow_pending = false;
     if (overlap && !pt.ev_shaded) {
         RT_HIP(c, hipEventCreateWithFlags(&pt.ev_shaded, hipEventDisableTiming));
@@ -258,6 +261,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         tm.begin(0);
         if (int rc = rt::launch_pt_generate(c, f, pt.st, pt.d_queue[0], pt.d_ctr)) return rc;
         tm.end();
+        bool shadow_deferred = false;  // fused mode: shadow(d - 1) waits for the launch of closest(d)
         for (uint32_t d = 0; d <= prm->bounces; d++) {
             uint32_t* ctr_d = pt.d_ctr + (size_t)rt::PT_CTR_STRIDE * d;
             uint32_t* ctr_n = pt.d_ctr + (size_t)rt::PT_CTR_STRIDE * (d + 1);
@@ -266,7 +270,15 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             tm.begin(1);
             if (d == 0 && !prm->tune_no_packet) {  // camera rays: one shared origin, coherent 4x4-pixel blocks per wave
                 if (int rc = rt::launch_pt_trace_packet(c, sc, f, pt.st, pt.d_stats, count)) return rc;
-            } else if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent, stack_cap, refill_min)) return rc;
+            } else if (shadow_deferred) {  // closest(d) + shadow(d - 1): ctr_d holds both the closest count of depth d and the shadow count of depth d - 1
+                if (int rc = rt::launch_pt_trace_fused(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, ctr_d + rt::PT_CTR_SHADOW_COUNT,
+                                                       ctr_d + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, count, grid_persistent, stack_cap, refill_min))
+                    return rc;
+                shadow_deferred = false;
+                launches_shadow++;
+            } else if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent, stack_cap, refill_min)) {
+                return rc;
+            }
             tm.end();
             launches_closest++;
             if (shadow_pending) {  // shade(d) adds sky/emission after shadow(d-1)'s contribution
@@ -274,13 +286,15 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
                 shadow_pending = false;
             }
             tm.begin(2);
-            if (int rc = rt::launch_pt_shade(c, sc, f, pt.st, q, ctr_d + rt::PT_CTR_COUNT, d, qn, ctr_n, grid_stride)) return rc;
+            if (int rc = rt::launch_pt_shade(c, sc, f, pt.st, q, ctr_d + rt::PT_CTR_COUNT, d, qn, ctr_n, grid_stride, prm->tune_sort_rays != 0)) return rc;
             tm.end();
             if (pt.n_lights) {
-                // shadow(d) only adds to the paths' radiance; closest(d+1) only reads rays: they are
-                // independent, so the shadow kernel runs on the auxiliary stream beside the next
-                // closest-hit kernel (each persistent kernel fills the other's tail).  shade(d+1) and
-                // resolve read the radiance and therefore wait for it (keeps the per-path sum order).
+                if (fused && d < prm->bounces) {  // goes into the same launch as closest(d + 1)
+                    shadow_deferred = true;
+                    continue;
+                }
+                // two-stream mode: the shadow kernel runs on the auxiliary stream beside the next closest-hit kernel;
+                // shade(d+1) and resolve read the radiance and therefore wait for it (keeps the per-path sum order)
                 rt::StackCfg sk2 = stack_cap;
                 hipStream_t main_stream = c->stream;
                 if (overlap) {
@@ -417,6 +431,7 @@ int rt_default_pt_params(rt_pt_params* p) {
     p->tune_lds_stack = 0;
     p->tune_no_overlap = 0;
     p->tune_no_packet = 0;
+    p->tune_sort_rays = 0;
     return RT_OK;
 }
 

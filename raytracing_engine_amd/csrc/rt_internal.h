@@ -261,9 +261,12 @@ int launch_to_rgba8(Ctx* c, const float* rgb, uint8_t* rgba, uint64_t n_pixels);
 int launch_pt_generate(Ctx* c, const PtFrame& f, const PtState& st, uint32_t* queue, uint32_t* ctr);
 int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head,
                     unsigned long long* stats, bool any_hit, bool count, uint32_t grid, const StackCfg& stack_cap, uint32_t refill_min);
+int launch_pt_trace_fused(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t* queue, const uint32_t* closest_count, uint32_t* closest_head,
+                          const uint32_t* shadow_count, uint32_t* shadow_head, unsigned long long* stats, bool count, uint32_t grid,
+                          const StackCfg& stack_cap, uint32_t refill_min);
 int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count);
 int launch_pt_shade(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr,
-                    uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid);
+                    uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid, bool sort_rays);
 int launch_pt_resolve(Ctx* c, const PtFrame& f, const PtState& st, float* acc, float* dst, int tile_major);
 int launch_pt_trace_rays(Ctx* c, const PtScene& sc, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out,
                          int* tri_out, uint32_t* counts, const StackCfg& sk, uint32_t grid);

@@ -303,13 +303,14 @@ class Renderer:
         self._check(self._lib.rt_set_mesh(self._ctx, _fptr(verts), _fptr(albedo), _fptr(emission), len(verts)))
 
     def pt_params(self, spp=4, bounces=1, seed=1, sky=(0.0, 0.0, 0.0), ray_eps=1e-3, count_traversal=False, max_paths=0, tune_refill_min=0,
-                  tune_blocks_per_cu=0, tune_lds_stack=0, tune_no_overlap=0, tune_no_packet=0):
+                  tune_blocks_per_cu=0, tune_lds_stack=0, tune_no_overlap=0, tune_no_packet=0, tune_sort_rays=0):
         p = PtParams()
         self._lib.rt_default_pt_params(C.byref(p))
         p.spp, p.bounces, p.seed, p.ray_eps, p.count_traversal, p.max_paths = spp, bounces, seed, ray_eps, int(count_traversal), max_paths
         p.tune_refill_min, p.tune_blocks_per_cu, p.tune_lds_stack = tune_refill_min, tune_blocks_per_cu, tune_lds_stack
         p.tune_no_overlap = tune_no_overlap
         p.tune_no_packet = tune_no_packet
+        p.tune_sort_rays = tune_sort_rays
         p.sky[:] = [float(np.float32(x)) for x in sky]
         return p
 

@@ -210,13 +210,21 @@ def test_shadow_overlap_does_not_change_results(renderer):
     v, a, e = scenes.cornell_tri_scene()
     renderer.set_mesh(v, a, e)
     renderer.resize(96, 96)
-    one = renderer.render_pt(pos=(0, 1, 0), spp=3, bounces=3, seed=8)
-    two = renderer.render_pt(pos=(0, 1, 0), spp=3, bounces=3, seed=8, tune_no_overlap=1)
-    assert np.array_equal(one, two)
+    one = renderer.render_pt(pos=(0, 1, 0), spp=3, bounces=3, seed=8)  # default: shadow(d) and closest(d + 1) in one persistent launch
+    st1 = renderer.pt_stats()
+    ref, ct = O.TriScene(v, a, e).render(96, 96, spp=3, bounces=3, seed=8, pos=(0, 1, 0))
+    assert np.array_equal(one, ref)
+    for mode in (1, 2):  # one launch after the other; two launches on two streams
+        two = renderer.render_pt(pos=(0, 1, 0), spp=3, bounces=3, seed=8, tune_no_overlap=mode)
+        st2 = renderer.pt_stats()
+        assert np.array_equal(one, two)
+        assert (st1["camera_rays"], st1["bounce_rays"], st1["shadow_rays"]) == (st2["camera_rays"], st2["bounce_rays"], st2["shadow_rays"]) == (ct["camera_rays"], ct["bounce_rays"], ct["shadow_rays"])
+    assert st1["launches_trace_closest"] == 4 and st1["launches_trace_shadow"] == 4
 
 
 @pytest.mark.parametrize("knobs", [dict(tune_refill_min=1), dict(tune_refill_min=64), dict(tune_refill_min=8 | (3 << 8)), dict(tune_blocks_per_cu=1),
-                                   dict(tune_blocks_per_cu=3, tune_lds_stack=2), dict(tune_lds_stack=1), dict(tune_lds_stack=40)])
+                                   dict(tune_blocks_per_cu=3, tune_lds_stack=2), dict(tune_lds_stack=1), dict(tune_lds_stack=40),
+                                   dict(tune_no_packet=1), dict(tune_sort_rays=1), dict(tune_sort_rays=1, tune_no_packet=1, tune_no_overlap=1)])
 def test_scheduling_knobs_do_not_change_the_frame(renderer, knobs):
     """Refill threshold, triangle tests per round, resident workgroups, LDS / spill split of the traversal
     stack: pure scheduling, so the frame and the ray counts must be identical to the default's."""
