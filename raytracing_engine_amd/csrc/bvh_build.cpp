@@ -374,13 +374,13 @@ inline float box_area(const float b[6]) {
 }
 
 // Binary SAH tree (one triangle per leaf) -> compressed 8-wide BVH (layout in bvh_build.h).
-// Which binary nodes become 8-wide nodes, which subtrees become <= 3-triangle leaves and how the 8
+// Which binary nodes become 8-wide nodes and how the 8 (every leaf is one triangle: bvh_build.h)
 // child slots of every node are spent is chosen by the dynamic program of Ylitie et al. 2017 (§4.1):
-//   C(n,1)   = min( A(n) P(n) c_prim  [P(n) <= 3],   A(n) c_node + D(n,8) )
+//   C(n,1)   = min( A(n) P(n) c_prim  [P(n) == 1],   A(n) c_node + D(n,8) )
 //   C(n,i>1) = min( D(n,i), C(n,i-1) ),   D(n,i) = min_{0<k<i} C(left,k) + C(right,i-k)
 // Nodes are emitted breadth-first so that the inner children of a node are consecutive
 // (child_base + rank among inner slots) and the triangles of its leaf children are consecutive
-// (tri_base + offset < 24).
+// (tri_base + rank among leaf slots).
 struct Cw8Builder {
     const std::vector<float>& n2;           // 16 floats per binary node
     const std::vector<uint32_t>& order2;    // binary leaf order -> triangle id
@@ -493,7 +493,7 @@ struct Cw8Builder {
                 d.split[i] = (uint8_t)bk;
             }
             const float area = box_area(d.box);
-            const float c_leaf = d.prims <= 3 ? area * (float)d.prims * kCostPrim : std::numeric_limits<float>::infinity();
+            const float c_leaf = d.prims <= 1 ? area * (float)d.prims * kCostPrim : std::numeric_limits<float>::infinity();  // leaves are single triangles
             const float c_int = D[8] + area * kCostNode;
             d.is_leaf = c_leaf <= c_int;
             d.cost[1] = d.is_leaf ? c_leaf : c_int;
@@ -648,22 +648,22 @@ struct Cw8Builder {
         w[3] = e_byte[0] | (e_byte[1] << 8) | (e_byte[2] << 16) | (imask << 24);
         w[4] = wk.child_base;
         w[5] = wk.tri_base;
-        uint8_t meta[8] = {}, q[6][8];
+        uint8_t q[6][8];
+        uint32_t leafmask = 0;
         for (int a = 0; a < 6; a++)
-            for (int s = 0; s < 8; s++) q[a][s] = a < 3 ? 255 : 0;  // empty slot: inverted box, meta 0
+            for (int s = 0; s < 8; s++) q[a][s] = a < 3 ? 255 : 0;  // empty slot: inverted box, in neither mask
         uint32_t rank = 0, off = 0;
         for (int s = 0; s < 8; s++) {
             const int i = child_in[s];
             if (i < 0) continue;
             if (ch[i].ref >= 0) {
-                meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
                 next_level[wk.child_base + rank - next_level_base] = Pending{ch[i].ref, wk.child_base + rank, wk.pd.level + 1};
                 rank++;
             } else {
-                const uint32_t ref = ~(uint32_t)ch[i].ref, first = ref >> 2, cnt = (ref & 3u) + 1u;  // cnt <= 3
-                meta[s] = (uint8_t)((((1u << cnt) - 1u) << 5) | off);
-                for (uint32_t t = 0; t < cnt; t++) order8[(size_t)wk.tri_base + off + t] = order2[first + t];
-                off += cnt;
+                const uint32_t ref = ~(uint32_t)ch[i].ref, first = ref >> 2;  // one triangle per leaf
+                leafmask |= 1u << s;
+                order8[(size_t)wk.tri_base + off] = order2[first];
+                off += 1;
             }
             for (int a = 0; a < 3; a++) {
                 double ql = std::floor(((double)ch[i].box[a] - (double)lo[a]) / scale[a]);
@@ -674,7 +674,8 @@ struct Cw8Builder {
                 q[3 + a][s] = (uint8_t)qh;
             }
         }
-        std::memcpy(&w[6], meta, 8);
+        w[6] = leafmask;
+        w[7] = 0;
         for (int a = 0; a < 6; a++) std::memcpy(&w[8 + 2 * a], q[a], 8);
     }
 
@@ -739,7 +740,7 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
     std::vector<float> binary;
     // conservative padding: absorbs the rounding of the slab test and of Moeller-Trumbore's t
     out->pad = 2e-5f * std::max(maxabs, 1.0f);
-    const uint32_t leaf_max = 1;  // the binary tree goes down to single triangles; the collapse forms the <= 3-triangle leaves
+    const uint32_t leaf_max = 1;  // the binary tree goes down to single triangles; the collapse keeps them as one-triangle leaves
     std::atomic<int> spare_threads{host_threads() - 1};
     Builder b{tri_box, centroid, out->order, binary, out->pad, max_depth, leaf_max, &spare_threads, host_threads()};
     out->sah_area = 0.0;

@@ -125,12 +125,14 @@ struct TravCounters {
 };
 
 // A traversal work item (Ylitie et al. 2017): either a node group  x = child_base,
-// y = hit bits of inner children in 31..24 | the parent's imask in 7..0;  or a triangle group
-// x = tri_base, y = hit bits of leaf triangles in 23..0.
+// y = hit bits of inner children in 31..24 (bit 24 + (slot ^ oct_inv): front to back) | the parent's imask in 7..0;
+// or a triangle group  x = tri_base, y = hit leaf slots in 7..0 | the node's leafmask in 15..8
+// (the triangle of leaf slot s is tri_base + popcount(leafmask below s), bvh_build.h).
 struct Group {
     uint32_t x, y;
 };
 __device__ __forceinline__ bool has_nodes(const Group& g) { return g.y > 0x00ffffffu; }
+__device__ __forceinline__ bool has_tris(const Group& t) { return (t.y & 0xffu) != 0u; }
 
 // Per-lane traversal stack of 8-byte groups.  The first `lds_cap` entries live in LDS (column of
 // this thread, stride 256 entries: conflict-free); the tree pushes at most one pending sibling
@@ -167,7 +169,7 @@ __device__ __forceinline__ float ubyte_f32(uint32_t w, int byte) {  // v_cvt_f32
 // loads for eight children), slab-test the eight quantised boxes and turn the hits into a new node
 // group (inner children, ordered by ray octant) and a triangle group (leaf triangles).
 template <bool COUNT>
-__device__ __forceinline__ void node_step(const float4* __restrict__ nodes, const TRay& r, Group& G, Group& T, TravStack& stk, TravCounters& tc) {
+__device__ __forceinline__ void node_step(const float4* __restrict__ nodes, const uint8_t* perm_lut, const TRay& r, Group& G, Group& T, TravStack& stk, TravCounters& tc) {
     const uint32_t hits = G.y;
     const uint32_t bit = 31u - (uint32_t)__builtin_clz(hits);
     G.y &= ~(1u << bit);
@@ -192,25 +194,11 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, cons
     const uint32_t nx[2] = {px ? lx[0] : hx[0], px ? lx[1] : hx[1]}, fx[2] = {px ? hx[0] : lx[0], px ? hx[1] : lx[1]};
     const uint32_t ny[2] = {py ? ly[0] : hy[0], py ? ly[1] : hy[1]}, fy[2] = {py ? hy[0] : ly[0], py ? hy[1] : ly[1]};
     const uint32_t nz[2] = {pz ? lz[0] : hz[0], pz ? lz[1] : hz[1]}, fz[2] = {pz ? hz[0] : lz[0], pz ? hz[1] : lz[1]};
-    // per-slot hit-mask fields, four slots per word: inner children (low 5 meta bits in 24..31) get
-    // bit 24 + (slot ^ oct_inv), leaves their unary triangle-count mask at their triangle offset
-    const uint32_t oct4 = __builtin_amdgcn_perm(0u, r.oct_inv, 0x00000000u);  // the octant byte in all four bytes (v_perm_b32, no multiply)
-    uint32_t bits4[2], pos4[2];
-#pragma unroll
-    for (int w = 0; w < 2; w++) {
-        const uint32_t m4 = __float_as_uint(w ? n1.w : n1.z);
-        const uint32_t inner4 = ((m4 & (m4 << 1)) & 0x10101010u) >> 4;  // 0x01 per inner slot
-        uint32_t inner7 = inner4 | (inner4 << 1);  // 0x07 per inner slot: the three slot bits the octant flips
-        __asm__ volatile("" : "+v"(inner7));     // (keeps the compiler from folding the two steps into a quarter-rate v_mul_lo_u32 by 7)
-        inner7 |= inner4 << 2;
-        pos4[w] = (m4 ^ (oct4 & inner7)) & 0x1f1f1f1fu;
-        bits4[w] = (m4 >> 5) & 0x07070707u;
-    }
     // No relative slack on the comparison: the build pads every box by 2e-5 * M (M = largest |coordinate|), at least five
     // times the rounding error of these fmas for ray origins within 32 M (render_pt_common checks the camera), so a box
     // that holds the ray's hit - or a (t, id) tie - always passes tn <= tf and tn <= tmax.
     const float tlim = r.tmax;
-    uint32_t hitmask = 0;
+    uint32_t h8 = 0;  // bit s: the box in child slot s is hit (empty slots hold inverted boxes)
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int w = i >> 2, bsel = i & 3;
@@ -219,21 +207,36 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, cons
         const float tnz = __builtin_fmaf(ubyte_f32(nz[w], bsel), az, bz), tfz = __builtin_fmaf(ubyte_f32(fz[w], bsel), az, bz);
         const float tn = fmax_(fmax_(tnx, tny), fmax_(tnz, 0.0f));
         const float tf = fmin_(fmin_(tfx, tfy), fmin_(tfz, tlim));
-        const uint32_t bits = (bits4[w] >> (8 * bsel)) & 0xffu, pos = (pos4[w] >> (8 * bsel)) & 0xffu;
-        if (tn <= tf) hitmask |= bits << pos;
+        if (tn <= tf) h8 |= 1u << i;
     }
+    // the hit bits are the work lists: inner children to enter, re-keyed front to back (bit slot -> bit slot ^ oct_inv,
+    // one byte from a 2 KiB LDS table), and the leaf slots whose single triangle is to be tested
+    const uint32_t leafmask = __float_as_uint(n1.z) & 0xffu;
+    const uint32_t keyed = perm_lut[r.oct_inv * 256u + (h8 & imask)];
     G.x = __float_as_uint(n1.x);
-    G.y = (hitmask & 0xff000000u) | imask;
+    G.y = (keyed << 24) | imask;
     T.x = __float_as_uint(n1.y);
-    T.y = hitmask & 0x00ffffffu;
+    T.y = (h8 & leafmask) | (leafmask << 8);
+}
+
+// perm_lut[o * 256 + m] = the byte m with bit s moved to bit s ^ o (8 octants x 256 masks), built once per workgroup
+__device__ __forceinline__ void build_perm_lut(uint8_t* lut) {
+    for (uint32_t i = threadIdx.x; i < 2048u; i += blockDim.x) {
+        const uint32_t o = i >> 8, m = i & 0xffu;
+        uint32_t out = 0;
+#pragma unroll
+        for (uint32_t sl = 0; sl < 8; sl++) out |= ((m >> sl) & 1u) << (sl ^ o);
+        lut[i] = (uint8_t)out;
+    }
+    __syncthreads();
 }
 
 // Test the next pending triangle of triangle group T.  Returns true when an any-hit ray found an occluder.
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool tri_step(const float4* __restrict__ tris, TRay& r, Hit& best, Group& T, TravCounters& tc) {
-    const uint32_t bit = (uint32_t)__builtin_ctz(T.y);
+    const uint32_t bit = (uint32_t)__builtin_ctz(T.y);  // lowest pending leaf slot (caller checked has_tris)
     T.y &= T.y - 1u;
-    const uint32_t li = T.x + bit;
+    const uint32_t li = T.x + (uint32_t)__builtin_popcount((T.y >> 8) & ~(0xffffffffu << bit));  // rank of the slot among the node's leaves
     const float4* tp = tris + (size_t)li * 3;
     const float4 a = tp[0], b = tp[1], c = tp[2];
     if (COUNT) tc.tris++;
@@ -256,8 +259,8 @@ __device__ __forceinline__ Group root_group() { return Group{0u, 0x80000000u}; }
 // Whole-ray traversal for one lane (used by the rt_trace_rays test hook; the render kernels drive
 // the same step functions from a refilling persistent loop).
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris, v3 o, v3 d, TravStack& stk, Hit& best,
-                                         TravCounters& tc) {
+__device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris, const uint8_t* perm_lut, v3 o, v3 d, TravStack& stk,
+                                         Hit& best, TravCounters& tc) {
     TRay r = make_tray(o, d, ANY ? kShadowTmax : best.t);
     stk.sp = 0;
     Group G = root_group(), T{0u, 0u};
@@ -266,8 +269,8 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const
             if (stk.sp == 0) return false;
             G = stk.pop();
         }
-        node_step<COUNT>(nodes, r, G, T, stk, tc);
-        while (T.y)
+        node_step<COUNT>(nodes, perm_lut, r, G, T, stk, tc);
+        while (has_tris(T))
             if (tri_step<ANY, COUNT>(tris, r, best, T, tc)) return true;
     }
 }
@@ -419,7 +422,7 @@ constexpr int kTrisPerRound = 1;
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st, const uint32_t* __restrict__ queue,
                                             const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
-                                            unsigned long long* __restrict__ stats, TravStack& stk, uint32_t refill_min) {
+                                            unsigned long long* __restrict__ stats, TravStack& stk, const uint8_t* perm_lut, uint32_t refill_min) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t n = *count_ptr;
@@ -497,17 +500,17 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
             alive_rounds += (uint32_t)__popcll(__ballot(alive));
         }
         // node phase: lanes without pending triangles visit their next node
-        if (alive && T.y == 0u) {
+        if (alive && !has_tris(T)) {
             if (!has_nodes(G)) {
                 if (stk.sp) G = stk.pop();
                 else alive = false;
             }
-            if (alive) node_step<COUNT>(sc.nodes, r, G, T, stk, tc);
+            if (alive) node_step<COUNT>(sc.nodes, perm_lut, r, G, T, stk, tc);
         }
         // triangle phase
 #pragma unroll 1
         for (int it = 0; it < tris_per_round; it++) {
-            if (alive && T.y != 0u) {
+            if (alive && has_tris(T)) {
                 if (tri_step<ANY, COUNT>(sc.tris, r, best, T, tc)) {
                     occluded = true;
                     alive = false;
@@ -539,9 +542,11 @@ __global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st,
                                                 const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
                                                 unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min) {
     extern __shared__ unsigned long long lds_stack[];  // sk.lds_cap x 256 entries
+    __shared__ uint8_t perm_lut[2048];
+    build_perm_lut(perm_lut);
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
     TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
-    trace_queue<ANY, COUNT>(sc, st, queue, count_ptr, head, stats, stk, refill_min);
+    trace_queue<ANY, COUNT>(sc, st, queue, count_ptr, head, stats, stk, perm_lut, refill_min);
 }
 
 // closest-hit rays of depth d + 1 and the shadow rays of depth d in ONE persistent launch: the two are independent (the
@@ -554,10 +559,12 @@ __global__ __launch_bounds__(256, 8) void pt_trace_fused(const PtScene sc, PtSta
                                                       const uint32_t* __restrict__ shadow_count, uint32_t* __restrict__ shadow_head,
                                                       unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min) {
     extern __shared__ unsigned long long lds_stack[];
+    __shared__ uint8_t perm_lut[2048];
+    build_perm_lut(perm_lut);
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
     TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
-    trace_queue<false, COUNT>(sc, st, queue, closest_count, closest_head, stats, stk, refill_min);
-    trace_queue<true, COUNT>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, refill_min);
+    trace_queue<false, COUNT>(sc, st, queue, closest_count, closest_head, stats, stk, perm_lut, refill_min);
+    trace_queue<true, COUNT>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, perm_lut, refill_min);
 }
 
 // ---- packet trace (camera rays) ---------------------------------------------------------------------
@@ -640,7 +647,7 @@ __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const P
             if (COUNT) n_nodes++;
             // header: wave-uniform address -> scalar loads
             const float px_ = __uint_as_float(nd[0]), py_ = __uint_as_float(nd[1]), pz_ = __uint_as_float(nd[2]);
-            const uint32_t w3 = nd[3], child_base = nd[4], tri_base = nd[5], m_lo = nd[6], m_hi = nd[7];
+            const uint32_t w3 = nd[3], child_base = nd[4], tri_base = nd[5], leafmask = nd[6] & 0xffu;
             const float sx = __uint_as_float((w3 & 0xffu) << 23), sy = __uint_as_float(((w3 >> 8) & 0xffu) << 23), sz = __uint_as_float(((w3 >> 16) & 0xffu) << 23);
             const uint32_t imask = w3 >> 24;
             // cooperative decode: one 48-byte vector load for the wave, world-space plane = p + q * scale
@@ -666,16 +673,9 @@ __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const P
             ih = (oct & 2u) ? (((ih & 0x33u) << 2) | ((ih >> 2) & 0x33u)) : ih;
             ih = (oct & 4u) ? (((ih & 0x0fu) << 4) | ((ih >> 4) & 0x0fu)) : ih;
             const uint32_t inner_hits = ih << 24;
-            uint32_t tri_mask = 0;
-            for (uint32_t lh = any & ~imask; lh; lh &= lh - 1u) {
+            for (uint32_t lh = any & leafmask; lh; lh &= lh - 1u) {  // the single triangles of the leaf slots some ray hit
                 const uint32_t c = (uint32_t)__builtin_ctz(lh);
-                const uint32_t m = ((c < 4u ? m_lo : m_hi) >> (8u * (c & 3u))) & 0xffu;
-                tri_mask |= (m >> 5) << (m & 0x1fu);
-            }
-            while (tri_mask) {
-                const uint32_t tb = (uint32_t)__builtin_ctz(tri_mask);
-                tri_mask &= tri_mask - 1u;
-                const uint32_t li = tri_base + tb;
+                const uint32_t li = tri_base + (uint32_t)__builtin_popcount(leafmask & ~(0xffffffffu << c));
                 const float* __restrict__ tp = reinterpret_cast<const float*>(sc.tris) + (size_t)li * 12u;  // wave-uniform: scalar loads
                 if (COUNT) n_tris++;
                 float t;
@@ -837,16 +837,17 @@ __global__ __launch_bounds__(256) void pt_resolve(const PtFrame f, PtState st, f
 // ---- test hook: trace a batch of caller-supplied rays ---------------------------------------------
 template <bool COUNT>
 __device__ __forceinline__ void trace_one_ray(const PtScene& sc, const float* __restrict__ origins, const float* __restrict__ dirs, uint32_t i,
-                                              int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out, TravStack& stk, TravCounters& tc) {
+                                              int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out, TravStack& stk, const uint8_t* perm_lut,
+                                              TravCounters& tc) {
     const v3 o = mk(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]), d = mk(dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2]);
     if (any_hit) {
         Hit h{kShadowTmax, -1, 0u};
-        const bool occ = traverse<true, COUNT>(sc.nodes, sc.tris, o, d, stk, h, tc);
+        const bool occ = traverse<true, COUNT>(sc.nodes, sc.tris, perm_lut, o, d, stk, h, tc);
         t_out[i] = occ ? 1.0f : 0.0f;
         tri_out[i] = occ ? 1 : 0;
     } else {
         Hit h{__builtin_inff(), -1, 0xffffffffu};
-        traverse<false, COUNT>(sc.nodes, sc.tris, o, d, stk, h, tc);
+        traverse<false, COUNT>(sc.nodes, sc.tris, perm_lut, o, d, stk, h, tc);
         t_out[i] = h.t;
         tri_out[i] = h.li < 0 ? -1 : (int)h.id;
     }
@@ -859,12 +860,14 @@ __global__ __launch_bounds__(256) void pt_trace_rays(const PtScene sc, const flo
                                                      int any_hit, float* __restrict__ t_out, int* __restrict__ tri_out, uint32_t* __restrict__ counts,
                                                      const StackCfg sk) {
     extern __shared__ unsigned long long lds_stack[];
+    __shared__ uint8_t perm_lut[2048];
+    build_perm_lut(perm_lut);
     // grid-stride so the spill columns (one per launched thread) stay within sk.spill_stride
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
     TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
     for (uint32_t i = (uint32_t)gtid; i < n; i += gridDim.x * 256u) {
         TravCounters tc{0, 0, 0};
-        trace_one_ray<COUNT>(sc, origins, dirs, i, any_hit, t_out, tri_out, stk, tc);
+        trace_one_ray<COUNT>(sc, origins, dirs, i, any_hit, t_out, tri_out, stk, perm_lut, tc);
         if (COUNT) {
             counts[2 * (size_t)i] = tc.nodes;
             counts[2 * (size_t)i + 1] = tc.tris;

@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
                 std::memcpy(&s[a], &bits, 4);
             }
             const uint32_t imask = w[3] >> 24, child_base = w[4], tri_base = w[5];
-            const uint8_t* meta = reinterpret_cast<const uint8_t*>(&w[6]);
+            const uint32_t leafmask = w[6] & 0xffu;  // bit s: slot s is a leaf = the one triangle tri_base + popcount(leafmask below s)
             const uint8_t* q = reinterpret_cast<const uint8_t*>(&w[8]);  // qlo.x[8] qlo.y[8] qlo.z[8] qhi.x[8] qhi.y[8] qhi.z[8]
             const float iv[3] = {inv.x, inv.y, inv.z}, nv[3] = {noi.x, noi.y, noi.z};
             float a_[3], b_[3];
@@ -119,10 +119,10 @@ int main(int argc, char** argv) {
             }
             const float tlim = tmax;  // the box padding is the slack (see node_step in csrc/path_b.hip)
             uint32_t inner_hit = 0;   // bit (slot ^ oct_inv): inner child in `slot` was hit
-            uint32_t tri_bits = 0;    // bit k: leaf triangle tri_base + k is to be tested
+            uint32_t leaf_hit = 0;    // bit slot: the leaf in `slot` was hit
             for (int slot = 0; slot < 8; slot++) {
-                const uint32_t m = meta[slot];
-                if (m == 0) continue;  // empty
+                const bool inner = (imask >> slot) & 1u, leaf = (leafmask >> slot) & 1u;
+                if (!inner && !leaf) continue;  // empty
                 float tn = 0.0f, tf = tlim;
                 for (int a = 0; a < 3; a++) {
                     const float lo = (float)q[8 * a + slot], hi = (float)q[24 + 8 * a + slot];
@@ -131,13 +131,13 @@ int main(int argc, char** argv) {
                     tf = std::fmin(tf, t_far);
                 }
                 if (!(tn <= tf)) continue;
-                if ((m >> 5) == 1u && (m & 0x1fu) >= 24u) inner_hit |= 1u << ((uint32_t)slot ^ oct_inv);  // inner: 001sssss, sssss = 24 + slot
-                else tri_bits |= (m >> 5) << (m & 0x1fu);                                              // leaf: unary count << offset
+                if (inner) inner_hit |= 1u << ((uint32_t)slot ^ oct_inv);
+                else leaf_hit |= 1u << slot;
             }
-            // leaf triangles first, in ascending leaf order
-            for (uint32_t k = 0; k < 24 && !occluded; k++) {
-                if (!((tri_bits >> k) & 1u)) continue;
-                const Tri& t = tris[tri_base + k];
+            // leaf triangles first, in ascending slot order
+            for (uint32_t k = 0; k < 8 && !occluded; k++) {
+                if (!((leaf_hit >> k) & 1u)) continue;
+                const Tri& t = tris[tri_base + (uint32_t)__builtin_popcount(leafmask & ((1u << k) - 1u))];
                 n_tris++;
                 float tt;
                 if (tri_test(o, d, t.v0, t.e1, t.e2, &tt) && tt > 0.0f) {

@@ -2,8 +2,8 @@
 // built with -fsanitize=address,undefined by tests/test_bvh_build_host.py.  No GPU involved.
 //   bvh_check <n_tris> <seed> <edge>
 // Verifies: the leaf order is a permutation; every triangle is reachable exactly once; inner-child
-// indexing (child_base + popcount(imask below slot)) and leaf encoding (unary count, offset < 24) are
-// consistent; every leaf triangle lies inside its de-quantised child box; depth <= stack_need - 1.
+// indexing (child_base + popcount(imask below slot)) and leaf indexing (one triangle per leaf slot, tri_base +
+// popcount(leafmask below slot)) are consistent; empty slots hold inverted boxes; every leaf triangle lies inside its de-quantised child box; depth <= stack_need - 1.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -58,32 +58,30 @@ int main(int argc, char** argv) {
         float scale[3];
         for (int a = 0; a < 3; a++) { const uint32_t bits = ((w[3] >> (8 * a)) & 0xffu) << 23; std::memcpy(&scale[a], &bits, 4); }
         const uint32_t imask = w[3] >> 24, child_base = w[4], tri_base = w[5];
-        const uint8_t* meta = reinterpret_cast<const uint8_t*>(&w[6]);
+        const uint32_t leafmask = w[6];
+        if (leafmask > 0xffu || w[7] != 0u || (leafmask & imask)) { std::puts("FAIL leafmask / reserved word"); return 1; }
         const uint8_t* q = reinterpret_cast<const uint8_t*>(&w[8]);  // [6][8]
         for (int slot = 0; slot < 8; slot++) {
-            const uint32_t m = meta[slot];
-            const bool inner = (imask >> slot) & 1u;
-            if (m == 0) { if (inner) { std::puts("FAIL empty slot flagged inner"); return 1; } continue; }
+            const bool inner = (imask >> slot) & 1u, leaf = (leafmask >> slot) & 1u;
+            if (!inner && !leaf) {  // empty slot: inverted box that no ray can hit
+                for (int a = 0; a < 3; a++)
+                    if (q[a * 8 + slot] != 255 || q[(3 + a) * 8 + slot] != 0) { std::puts("FAIL empty slot without an inverted box"); return 1; }
+                continue;
+            }
             float lo[3], hi[3];
             for (int a = 0; a < 3; a++) { lo[a] = p[a] + (float)q[a * 8 + slot] * scale[a]; hi[a] = p[a] + (float)q[(3 + a) * 8 + slot] * scale[a]; }
             if (inner) {
-                if ((m >> 5) != 1u || (m & 31u) != 24u + (uint32_t)slot) { std::puts("FAIL inner meta"); return 1; }
                 const uint32_t rel = (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u));
                 stack.push_back({child_base + rel, it.level + 1});
-            } else {
-                const uint32_t bits = m >> 5, off = m & 31u;
-                const uint32_t cnt = bits == 1 ? 1 : bits == 3 ? 2 : bits == 7 ? 3 : 0;
-                if (!cnt || off + cnt > 24) { std::puts("FAIL leaf meta"); return 1; }
-                for (uint32_t k = 0; k < cnt; k++) {
-                    const uint32_t li = tri_base + off + k;
-                    if (li >= n) { std::puts("FAIL leaf triangle index"); return 1; }
-                    const uint32_t t = b.order[li];
-                    reached[t]++;
-                    for (int a = 0; a < 3; a++) {
-                        const float x0 = v0[3 * (size_t)t + a], x1 = x0 + e1[3 * (size_t)t + a], x2 = x0 + e2[3 * (size_t)t + a];
-                        const float mn = std::fmin(x0, std::fmin(x1, x2)), mx = std::fmax(x0, std::fmax(x1, x2));
-                        if (mn < lo[a] || mx > hi[a]) { std::printf("FAIL triangle %u outside its leaf box on axis %d\n", t, a); return 1; }
-                    }
+            } else {  // a leaf is one triangle: tri_base + rank of the slot among the node's leaf slots
+                const uint32_t li = tri_base + (uint32_t)__builtin_popcount(leafmask & ((1u << slot) - 1u));
+                if (li >= n) { std::puts("FAIL leaf triangle index"); return 1; }
+                const uint32_t t = b.order[li];
+                reached[t]++;
+                for (int a = 0; a < 3; a++) {
+                    const float x0 = v0[3 * (size_t)t + a], x1 = x0 + e1[3 * (size_t)t + a], x2 = x0 + e2[3 * (size_t)t + a];
+                    const float mn = std::fmin(x0, std::fmin(x1, x2)), mx = std::fmax(x0, std::fmax(x1, x2));
+                    if (mn < lo[a] || mx > hi[a]) { std::printf("FAIL triangle %u outside its leaf box on axis %d\n", t, a); return 1; }
                 }
             }
         }
