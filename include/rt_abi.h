@@ -250,13 +250,35 @@ typedef struct rt_pt_stats {
     float ms_generate, ms_trace_closest, ms_shade, ms_trace_shadow, ms_resolve; /* profile_stages = 1 only */
     uint32_t launches_trace_closest, launches_trace_shadow;
     uint64_t packets;          /* camera-ray waves walked by the packet kernel; last render, count_traversal = 1 only */
+    uint32_t bvh_levels, blas_chunks, tlas_nodes; /* 1 / 0 / 0 for a single-level mesh */
+    float ms_build_blas, ms_build_tlas, ms_build_flatten; /* two-level meshes: phases of the last build or chunk rebuild (bvh_build_ms = all of it) */
 } rt_pt_stats;
+
+/* How rt_set_mesh_ex builds the acceleration structure.  bvh_levels = 1: one BVH8 over all triangles (rt_set_mesh).
+ * bvh_levels = 2 (BASELINE.json configs[2] "2-level BVH"): the triangles are cut into blas_chunks runs of their
+ * centroids' Morton order (0 = 64), every run gets a bottom-level BVH8 of its own, a top-level BVH8 is built over the
+ * chunk boxes, and both levels are flattened into the one node array the kernels traverse.  Frames are identical either
+ * way (results do not depend on the tree); the two-level mesh can have one chunk's vertices replaced and only that
+ * chunk rebuilt (rt_update_mesh_chunk). */
+typedef struct rt_mesh_options {
+    uint32_t bvh_levels;  /* 1 or 2 */
+    uint32_t blas_chunks; /* bvh_levels = 2: number of bottom-level chunks, 0 = 64 (at least four triangles per chunk) */
+} rt_mesh_options;
 
 int rt_default_pt_params(rt_pt_params* p);
 /* verts: n_tris*9 (v0,v1,v2), albedo: n_tris*3, emission: n_tris*3 (any component > 0 = light).
  * Uploads the mesh and builds the BVH on the host (binned SAH -> compressed 8-wide nodes, threaded; the result does
  * not depend on the thread count).  Host pointers, copied. */
 int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const float* emission, uint32_t n_tris);
+/* rt_set_mesh with build options (options == NULL: rt_set_mesh). */
+int rt_set_mesh_ex(rt_ctx* ctx, const float* verts, const float* albedo, const float* emission, uint32_t n_tris, const rt_mesh_options* options);
+/* Two-level meshes: the triangles of bottom-level chunk `chunk` (count, and their original indices into tri_ids[capacity]
+ * when tri_ids != NULL), in the order rt_update_mesh_chunk expects their vertices. */
+int rt_mesh_chunk_info(rt_ctx* ctx, uint32_t chunk, uint32_t* count, uint32_t* tri_ids, uint32_t capacity);
+/* Two-level meshes: replace the vertices of one chunk's triangles (count * 9 floats, rt_mesh_chunk_info order; materials
+ * and chunk membership stay) and rebuild that chunk's BVH, the top level and the flattened node array only.  The new
+ * vertices must stay within the coordinate range of the mesh as first set (RT_ERR_INVALID otherwise: set the mesh again). */
+int rt_update_mesh_chunk(rt_ctx* ctx, uint32_t chunk, const float* verts);
 /* Synchronous path-traced frame of the current view (rt_resize) into host memory.
  * Every |pos| component must be <= 32 x max(1, largest |vertex coordinate| of the mesh): that is the range
  * over which the BVH's conservative box padding covers the fp32 rounding of the ray/box test (beyond it the

@@ -67,6 +67,10 @@ class PtParams(C.Structure):  # rt_pt_params
                 ("tune_no_packet", C.c_uint32), ("tune_sort_rays", C.c_uint32)]
 
 
+class MeshOptions(C.Structure):  # rt_mesh_options
+    _fields_ = [("bvh_levels", C.c_uint32), ("blas_chunks", C.c_uint32)]
+
+
 class PtStats(C.Structure):  # rt_pt_stats
     _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("n_lights", C.c_uint32),
                 ("stack_need", C.c_uint32), ("bvh_build_ms", C.c_float), ("stack_overflow", C.c_uint32), ("camera_rays", C.c_uint64),
@@ -76,7 +80,8 @@ class PtStats(C.Structure):  # rt_pt_stats
                 ("ms_total", C.c_float), ("ms_generate", C.c_float),
                 ("ms_trace_closest", C.c_float), ("ms_shade", C.c_float), ("ms_trace_shadow", C.c_float),
                 ("ms_resolve", C.c_float), ("launches_trace_closest", C.c_uint32), ("launches_trace_shadow", C.c_uint32),
-                ("packets", C.c_uint64)]
+                ("packets", C.c_uint64), ("bvh_levels", C.c_uint32), ("blas_chunks", C.c_uint32), ("tlas_nodes", C.c_uint32),
+                ("ms_build_blas", C.c_float), ("ms_build_tlas", C.c_float), ("ms_build_flatten", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -117,6 +122,9 @@ PROTOTYPES = {
     "rt_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "rt_default_pt_params": (C.c_int, [C.POINTER(PtParams)]),
     "rt_set_mesh": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32]),
+    "rt_set_mesh_ex": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32, C.POINTER(MeshOptions)]),
+    "rt_mesh_chunk_info": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, C.c_uint32]),
+    "rt_update_mesh_chunk": (C.c_int, [_vp, C.c_uint32, _fp]),
     "rt_render_pt": (C.c_int, [_vp, _fp, _fp, C.POINTER(PtParams), _fp]),
     "rt_render_pt_device": (C.c_int, [_vp, _fp, _fp, C.POINTER(PtParams), _vp, C.c_int]),
     "rt_get_pt_stats": (C.c_int, [_vp, C.POINTER(PtStats)]),

@@ -399,6 +399,8 @@ struct Cw8Builder {
         float box[6];
     };
     std::vector<Dp> dp;
+    int max_threads = 0;  // 0 = every CPU the process may use
+    int thread_count() const { return max_threads > 0 ? std::min(max_threads, host_threads()) : host_threads(); }
 
     void child_box(int32_t node2, int side, float out[6]) const { std::memcpy(out, &n2[(size_t)node2 * 16 + 6 * side], 24); }
     int32_t child_ref(int32_t node2, int side) const {
@@ -413,7 +415,7 @@ struct Cw8Builder {
     void solve() {
         const size_t n_nodes = n2.size() / 16;
         dp.resize(n_nodes);
-        const int threads = host_threads();
+        const int threads = thread_count();
         struct Range {
             size_t lo, hi;
         };
@@ -684,7 +686,7 @@ struct Cw8Builder {
         solve();
         RT_BVH_T(t1);
         RT_BVH_REPORT("  collapse: DP", t0, t1);
-        const int threads = host_threads();
+        const int threads = thread_count();
         nodes.clear();
         order8.clear();
         std::vector<Pending> level{Pending{0, 0, 0}}, next;
@@ -739,10 +741,11 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
     for (uint32_t i = 0; i < n; i++) out->order[i] = i;
     std::vector<float> binary;
     // conservative padding: absorbs the rounding of the slab test and of Moeller-Trumbore's t
-    out->pad = 2e-5f * std::max(maxabs, 1.0f);
+    out->pad = out->pad_in >= 0.0f ? out->pad_in : 2e-5f * std::max(maxabs, 1.0f);
     const uint32_t leaf_max = 1;  // the binary tree goes down to single triangles; the collapse keeps them as one-triangle leaves
-    std::atomic<int> spare_threads{host_threads() - 1};
-    Builder b{tri_box, centroid, out->order, binary, out->pad, max_depth, leaf_max, &spare_threads, host_threads()};
+    const int threads = out->max_threads > 0 ? std::min(out->max_threads, host_threads()) : host_threads();
+    std::atomic<int> spare_threads{threads - 1};
+    Builder b{tri_box, centroid, out->order, binary, out->pad, max_depth, leaf_max, &spare_threads, threads};
     out->sah_area = 0.0;
     if (n <= leaf_max) {
         // one node whose two slots name the same leaf (testing it twice is idempotent)
@@ -772,7 +775,7 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
     std::vector<uint32_t> order2;
     order2.swap(out->order);
     out->order.reserve(n);
-    Cw8Builder cw{binary, order2, out->nodes, out->order, 0, out->cost_prim, {}};
+    Cw8Builder cw{binary, order2, out->nodes, out->order, 0, out->cost_prim, {}, threads};
     RT_BVH_T(t_c0);
     cw.build();
     RT_BVH_T(t_c1);

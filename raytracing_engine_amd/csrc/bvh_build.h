@@ -28,6 +28,9 @@ struct BvhResult {
     std::vector<uint32_t> order;  // leaf-order position -> original triangle index
     float cost_prim = 0.8f;       // in: SAH cost of a triangle test relative to a node visit (collapse DP);
                                   // measured on the bench scene: 0.3 -> 1615, 0.6 -> 1794, 1.0 -> 1799 Mrays/s
+    float pad_in = -1.0f;         // in: >= 0: use this box padding instead of 2e-5 * max(largest |coordinate|, 1) (the chunks of a two-level
+                                  // build share the whole mesh's padding)
+    int max_threads = 0;          // in: > 0: use at most this many threads (the chunks of a two-level build are built side by side)
     uint32_t n_nodes = 0;
     uint32_t depth = 0;           // levels of 8-wide inner nodes (root = 1)
     uint32_t stack_need = 0;      // worst-case traversal stack occupancy (entries)
@@ -39,5 +42,24 @@ constexpr uint32_t kBvhMaxDepth = 30;  // depth cap of the binary tree before it
 
 // v0/e1/e2: n*3 floats each (edges already formed in fp32).  Returns false on invalid input.
 bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, uint32_t max_depth, BvhResult* out);
+
+// Two-level build ("TLAS over BLAS chunks", BASELINE.json configs[2]): the triangles are sorted along the Morton curve of
+// their centroids and cut into `chunks` equal runs, each run gets a BVH of its own (a bottom-level structure, build_bvh),
+// and a top-level BVH8 is built over the chunk boxes.  The result is flattened into ONE node array of the same format - a
+// top-level leaf simply becomes an inner child that is the chunk's root - so the traversal kernels do not know the
+// difference; what the split buys is that a chunk whose triangles moved is rebuilt alone (rebuild_chunk): 1/chunks of the
+// binned-SAH work plus a microscopic top level, then a re-flatten.
+struct TwoLevelBvh {
+    std::vector<BvhResult> blas;            // per chunk, local node / triangle indices
+    std::vector<uint32_t> sorted;           // Morton order -> original triangle index; chunk c owns sorted[first[c] .. first[c + 1])
+    std::vector<uint32_t> first;            // chunks + 1 entries
+    float pad = 0.0f;
+    uint32_t tlas_nodes = 0, tlas_depth = 0;
+    double ms_blas = 0.0, ms_tlas = 0.0, ms_flatten = 0.0;  // wall time of the last (re)build's phases
+};
+bool build_bvh_two_level(const float* v0, const float* e1, const float* e2, uint32_t n, uint32_t chunks, uint32_t max_depth, TwoLevelBvh* tl, BvhResult* out);
+// Rebuild bottom-level structure `chunk` from the current vertex data (v0/e1/e2 of the WHOLE mesh, original triangle order;
+// the chunk keeps its triangles), rebuild the top level over the new chunk boxes and flatten again into `out`.
+bool rebuild_chunk(const float* v0, const float* e1, const float* e2, uint32_t n, uint32_t chunk, uint32_t max_depth, TwoLevelBvh* tl, BvhResult* out);
 
 }  // namespace rt

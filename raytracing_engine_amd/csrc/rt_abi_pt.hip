@@ -63,6 +63,8 @@ void free_mesh(PtData& pt) {
     dfree(pt.d_lights);
     dfree(pt.d_spill);
     pt.spill_words = 0;
+    pt.host.reset();
+    pt.cap_nodes = 0;
     pt.n_tris = pt.n_nodes = pt.n_lights = 0;
 }
 
@@ -438,9 +440,46 @@ int rt_default_pt_params(rt_pt_params* p) {
 }  // extern "C"
 
 namespace {
-int set_mesh_impl(Ctx* c, const float* verts, const float* albedo, const float* emission, uint32_t n_tris) {
+
+// leaf-order records [li0, li1) of the device triangle / material arrays from the host copies
+void pack_leaf_range(const rt::BvhResult& bvh, const float* v0, const float* e1, const float* e2, const float* albedo, const float* emission, size_t li0,
+                     size_t li1, float* tris, float* alb, float* emi) {
+    for (size_t li = li0; li < li1; li++) {
+        const uint32_t t = bvh.order[li];
+        float* r = &tris[12 * (li - li0)];
+        r[0] = v0[3 * (size_t)t]; r[1] = v0[3 * (size_t)t + 1]; r[2] = v0[3 * (size_t)t + 2]; r[3] = e1[3 * (size_t)t];
+        r[4] = e1[3 * (size_t)t + 1]; r[5] = e1[3 * (size_t)t + 2]; r[6] = e2[3 * (size_t)t]; r[7] = e2[3 * (size_t)t + 1];
+        r[8] = e2[3 * (size_t)t + 2];
+        std::memcpy(&r[9], &t, 4);
+        r[10] = r[11] = 0.0f;
+        for (int a = 0; a < 3; a++) {
+            alb[4 * (li - li0) + a] = albedo[3 * (size_t)t + a];
+            emi[4 * (li - li0) + a] = emission[3 * (size_t)t + a];
+        }
+        alb[4 * (li - li0) + 3] = emi[4 * (li - li0) + 3] = 0.0f;
+    }
+}
+
+void publish_bvh_stats(PtData& pt, const rt::BvhResult& bvh) {
+    pt.n_nodes = bvh.n_nodes;
+    pt.bvh_depth = bvh.depth;
+    pt.stack_need = bvh.stack_need;
+    pt.bvh_pad = bvh.pad;
+    pt.stats.n_nodes = bvh.n_nodes;
+    pt.stats.bvh_depth = bvh.depth;
+    pt.stats.stack_need = bvh.stack_need;
+    pt.stats.bvh_build_ms = pt.bvh_build_ms;
+    pt.stats.bvh_levels = pt.host ? 2u : 1u;
+    pt.stats.blas_chunks = pt.host ? (uint32_t)pt.host->tl.blas.size() : 0u;
+    pt.stats.tlas_nodes = pt.host ? pt.host->tl.tlas_nodes : 0u;
+}
+
+int set_mesh_impl(Ctx* c, const float* verts, const float* albedo, const float* emission, uint32_t n_tris, const rt_mesh_options* opt) {
     if (!verts || !albedo || !emission) return c->fail(RT_ERR_INVALID, "mesh arrays must not be NULL");
     if (n_tris == 0 || n_tris >= (1u << 28)) return c->fail(RT_ERR_INVALID, "n_tris %u out of [1, 2^28)", n_tris);
+    const uint32_t levels = opt ? opt->bvh_levels : 1u, chunks = opt && opt->blas_chunks ? opt->blas_chunks : 64u;
+    if (levels != 1u && levels != 2u) return c->fail(RT_ERR_INVALID, "bvh_levels %u (1 or 2)", levels);
+    if (chunks > 65536u) return c->fail(RT_ERR_INVALID, "blas_chunks %u > 65536", chunks);
     for (size_t i = 0; i < (size_t)n_tris * 9; i++)
         if (!std::isfinite(verts[i])) return c->fail(RT_ERR_INVALID, "vertex data is not finite at float %zu", i);
     if (int rc = bind(c)) return rc;
@@ -452,7 +491,7 @@ int set_mesh_impl(Ctx* c, const float* verts, const float* albedo, const float* 
     c->state_version++;
 
     const size_t n = n_tris;
-    // spec §6.1: edges are formed once, in fp32
+    // spec section 6.1: edges are formed once, in fp32
     std::vector<float> v0(3 * n), e1(3 * n), e2(3 * n);
     for (size_t i = 0; i < n; i++)
         for (int a = 0; a < 3; a++) {
@@ -462,32 +501,32 @@ int set_mesh_impl(Ctx* c, const float* verts, const float* albedo, const float* 
         }
     const auto t0 = std::chrono::steady_clock::now();
     rt::BvhResult bvh;
-    if (!rt::build_bvh(v0.data(), e1.data(), e2.data(), n_tris, rt::kBvhMaxDepth, &bvh)) return c->fail(RT_ERR_INVALID, "BVH build failed");
+    if (levels == 2u) {
+        pt.host.reset(new rt::MeshHost());
+        if (!rt::build_bvh_two_level(v0.data(), e1.data(), e2.data(), n_tris, chunks, rt::kBvhMaxDepth, &pt.host->tl, &bvh)) {
+            pt.host.reset();
+            return c->fail(RT_ERR_INVALID, "two-level BVH build failed");
+        }
+    } else if (!rt::build_bvh(v0.data(), e1.data(), e2.data(), n_tris, rt::kBvhMaxDepth, &bvh)) {
+        return c->fail(RT_ERR_INVALID, "BVH build failed");
+    }
     pt.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
     // leaf-order triangle records + materials; lights in ascending original index
     std::vector<float> tris(12 * n), alb(4 * n), emi(4 * n);
+    pack_leaf_range(bvh, v0.data(), e1.data(), e2.data(), albedo, emission, 0, n, tris.data(), alb.data(), emi.data());
     std::vector<uint32_t> leaf_pos(n);
-    for (size_t li = 0; li < n; li++) {
-        const uint32_t t = bvh.order[li];
-        leaf_pos[t] = (uint32_t)li;
-        float* r = &tris[12 * li];
-        r[0] = v0[3 * t]; r[1] = v0[3 * t + 1]; r[2] = v0[3 * t + 2]; r[3] = e1[3 * t];
-        r[4] = e1[3 * t + 1]; r[5] = e1[3 * t + 2]; r[6] = e2[3 * t]; r[7] = e2[3 * t + 1];
-        r[8] = e2[3 * t + 2];
-        std::memcpy(&r[9], &t, 4);
-        r[10] = r[11] = 0.0f;
-        for (int a = 0; a < 3; a++) {
-            alb[4 * li + a] = albedo[3 * (size_t)t + a];
-            emi[4 * li + a] = emission[3 * (size_t)t + a];
-        }
-        alb[4 * li + 3] = emi[4 * li + 3] = 0.0f;
-    }
-    std::vector<uint32_t> lights;
+    for (size_t li = 0; li < n; li++) leaf_pos[bvh.order[li]] = (uint32_t)li;
+    std::vector<uint32_t> lights, light_ids;
     for (size_t t = 0; t < n; t++)
-        if (emission[3 * t] > 0.0f || emission[3 * t + 1] > 0.0f || emission[3 * t + 2] > 0.0f) lights.push_back(leaf_pos[t]);
+        if (emission[3 * t] > 0.0f || emission[3 * t + 1] > 0.0f || emission[3 * t + 2] > 0.0f) {
+            lights.push_back(leaf_pos[t]);
+            light_ids.push_back((uint32_t)t);
+        }
 
-    const bool ok = dalloc(pt.d_nodes, (size_t)bvh.n_nodes * 5) && dalloc(pt.d_tris, n * 3) && dalloc(pt.d_albedo, n) && dalloc(pt.d_emission, n) &&
+    // a two-level mesh keeps room for the node count to move when a chunk is rebuilt
+    pt.cap_nodes = levels == 2u ? (size_t)bvh.n_nodes + bvh.n_nodes / 8 + 1024 : bvh.n_nodes;
+    const bool ok = dalloc(pt.d_nodes, pt.cap_nodes * 5) && dalloc(pt.d_tris, n * 3) && dalloc(pt.d_albedo, n) && dalloc(pt.d_emission, n) &&
                     dalloc(pt.d_lights, std::max<size_t>(lights.size(), 1));
     if (!ok) {
         free_mesh(pt);
@@ -499,44 +538,158 @@ int set_mesh_impl(Ctx* c, const float* verts, const float* albedo, const float* 
     RT_HIP(c, hipMemcpy(pt.d_emission, emi.data(), n * 16, hipMemcpyHostToDevice));
     if (!lights.empty()) RT_HIP(c, hipMemcpy(pt.d_lights, lights.data(), lights.size() * 4, hipMemcpyHostToDevice));
     pt.n_tris = n_tris;
-    pt.n_nodes = bvh.n_nodes;
     pt.n_lights = (uint32_t)lights.size();
-    pt.bvh_depth = bvh.depth;
-    pt.stack_need = bvh.stack_need;
-    pt.bvh_pad = bvh.pad;
     pt.stats = rt_pt_stats{};
     pt.stats.n_tris = n_tris;
-    pt.stats.n_nodes = bvh.n_nodes;
-    pt.stats.bvh_depth = bvh.depth;
-    pt.stats.stack_need = bvh.stack_need;
     pt.stats.n_lights = pt.n_lights;
-    pt.stats.bvh_build_ms = pt.bvh_build_ms;
+    if (pt.host) {  // what a chunk rebuild needs: the mesh in original order and where the lights are
+        pt.host->v0.swap(v0);
+        pt.host->e1.swap(e1);
+        pt.host->e2.swap(e2);
+        pt.host->albedo.assign(albedo, albedo + 3 * n);
+        pt.host->emission.assign(emission, emission + 3 * n);
+        pt.host->light_ids.swap(light_ids);
+        pt.stats.ms_build_blas = (float)pt.host->tl.ms_blas;
+        pt.stats.ms_build_tlas = (float)pt.host->tl.ms_tlas;
+        pt.stats.ms_build_flatten = (float)pt.host->tl.ms_flatten;
+    }
+    publish_bvh_stats(pt, bvh);
     return RT_OK;
+}
+
+int update_chunk_impl(Ctx* c, uint32_t chunk, const float* verts) {
+    PtData& pt = c->pt;
+    if (!pt.host || pt.borrowed_mesh) return c->fail(RT_ERR_STATE, "rt_update_mesh_chunk needs a two-level mesh (rt_set_mesh_ex with bvh_levels = 2) owned by this context");
+    rt::MeshHost& h = *pt.host;
+    if (chunk >= h.tl.blas.size()) return c->fail(RT_ERR_INVALID, "chunk %u of %zu", chunk, h.tl.blas.size());
+    if (!verts) return c->fail(RT_ERR_INVALID, "verts is NULL");
+    const uint32_t first = h.tl.first[chunk], count = h.tl.first[chunk + 1] - first;
+    for (size_t i = 0; i < (size_t)count * 9; i++)
+        if (!std::isfinite(verts[i])) return c->fail(RT_ERR_INVALID, "vertex data is not finite at float %zu", i);
+    if (int rc = bind(c)) return rc;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->aux_stream) RT_HIP(c, hipStreamSynchronize(c->aux_stream));
+    rt::frames_drop_mesh(c);  // lanes re-borrow the mesh on their next submit
+    c->state_version++;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<float> old((size_t)count * 9);  // to restore the host copy if the rebuild is refused
+    for (uint32_t i = 0; i < count; i++) {
+        const size_t t = h.tl.sorted[first + i];
+        for (int a = 0; a < 3; a++) {
+            old[9 * (size_t)i + a] = h.v0[3 * t + a];
+            old[9 * (size_t)i + 3 + a] = h.e1[3 * t + a];
+            old[9 * (size_t)i + 6 + a] = h.e2[3 * t + a];
+            h.v0[3 * t + a] = verts[9 * (size_t)i + a];
+            h.e1[3 * t + a] = verts[9 * (size_t)i + 3 + a] - verts[9 * (size_t)i + a];
+            h.e2[3 * t + a] = verts[9 * (size_t)i + 6 + a] - verts[9 * (size_t)i + a];
+        }
+    }
+    rt::BvhResult bvh;
+    const uint32_t n = pt.n_tris;
+    if (!rt::rebuild_chunk(h.v0.data(), h.e1.data(), h.e2.data(), n, chunk, rt::kBvhMaxDepth, &h.tl, &bvh)) {
+        for (uint32_t i = 0; i < count; i++) {
+            const size_t t = h.tl.sorted[first + i];
+            for (int a = 0; a < 3; a++) {
+                h.v0[3 * t + a] = old[9 * (size_t)i + a];
+                h.e1[3 * t + a] = old[9 * (size_t)i + 3 + a];
+                h.e2[3 * t + a] = old[9 * (size_t)i + 6 + a];
+            }
+        }
+        return c->fail(RT_ERR_INVALID, "chunk rebuild refused: the moved vertices leave the coordinate range the mesh's box padding was chosen for (call rt_set_mesh_ex again)");
+    }
+    pt.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (bvh.n_nodes > pt.cap_nodes) {
+        dfree(pt.d_nodes);
+        pt.cap_nodes = (size_t)bvh.n_nodes + bvh.n_nodes / 8 + 1024;
+        if (!dalloc(pt.d_nodes, pt.cap_nodes * 5)) {
+            free_mesh(pt);
+            return c->fail(RT_ERR_OOM, "node array of %u nodes", bvh.n_nodes);
+        }
+    }
+    // the chunk's triangles keep their range of the leaf order (chunks are laid out in chunk order); inside it the order is new
+    size_t li0 = 0;
+    for (uint32_t b = 0; b < chunk; b++) li0 += h.tl.blas[b].order.size();
+    const size_t li1 = li0 + count;
+    std::vector<float> tris(12 * (size_t)count), alb(4 * (size_t)count), emi(4 * (size_t)count);
+    pack_leaf_range(bvh, h.v0.data(), h.e1.data(), h.e2.data(), h.albedo.data(), h.emission.data(), li0, li1, tris.data(), alb.data(), emi.data());
+    RT_HIP(c, hipMemcpy(pt.d_nodes, bvh.nodes.data(), (size_t)bvh.n_nodes * 80, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(pt.d_tris + li0 * 3, tris.data(), (size_t)count * 48, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(pt.d_albedo + li0, alb.data(), (size_t)count * 16, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(pt.d_emission + li0, emi.data(), (size_t)count * 16, hipMemcpyHostToDevice));
+    if (!h.light_ids.empty()) {  // lights are listed by leaf position, in ascending original index
+        std::vector<uint32_t> leaf_of(h.light_ids.size(), 0u);
+        bool moved = false;
+        for (size_t li = li0; li < li1; li++) {
+            const auto it = std::lower_bound(h.light_ids.begin(), h.light_ids.end(), bvh.order[li]);
+            if (it != h.light_ids.end() && *it == bvh.order[li]) moved = true;
+        }
+        if (moved) {
+            std::vector<uint32_t> leaf_pos(n);
+            for (size_t li = 0; li < n; li++) leaf_pos[bvh.order[li]] = (uint32_t)li;
+            for (size_t k = 0; k < h.light_ids.size(); k++) leaf_of[k] = leaf_pos[h.light_ids[k]];
+            RT_HIP(c, hipMemcpy(pt.d_lights, leaf_of.data(), leaf_of.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    pt.stats.ms_build_blas = (float)h.tl.ms_blas;
+    pt.stats.ms_build_tlas = (float)h.tl.ms_tlas;
+    pt.stats.ms_build_flatten = (float)h.tl.ms_flatten;
+    publish_bvh_stats(pt, bvh);
+    return RT_OK;
+}
+
+template <class F>
+int guarded(Ctx* c, const char* what, F&& f) {
+    // the builder allocates host vectors sized by n_tris and starts std::threads: nothing may leave an entry point
+    // as a C++ exception (include/rt_abi.h: never throws or aborts across the boundary)
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        free_mesh(c->pt);
+        return c->fail(RT_ERR_OOM, "%s: out of host memory", what);
+    } catch (const std::system_error& e) {
+        free_mesh(c->pt);
+        return c->fail(RT_ERR_STATE, "%s: %s", what, e.what());
+    } catch (const std::exception& e) {
+        free_mesh(c->pt);
+        return c->fail(RT_ERR_INVALID, "%s: %s", what, e.what());
+    } catch (...) {
+        free_mesh(c->pt);
+        return c->fail(RT_ERR_INVALID, "%s failed", what);
+    }
 }
 }  // namespace
 
 extern "C" {
 
 int rt_set_mesh(rt_ctx* ctx, const float* verts, const float* albedo, const float* emission, uint32_t n_tris) {
+    return rt_set_mesh_ex(ctx, verts, albedo, emission, n_tris, nullptr);
+}
+
+int rt_set_mesh_ex(rt_ctx* ctx, const float* verts, const float* albedo, const float* emission, uint32_t n_tris, const rt_mesh_options* options) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return RT_ERR_INVALID;
-    // the builder allocates host vectors sized by n_tris and starts std::threads: nothing may leave this
-    // function as a C++ exception (include/rt_abi.h: never throws or aborts across the boundary)
-    try {
-        return set_mesh_impl(c, verts, albedo, emission, n_tris);
-    } catch (const std::bad_alloc&) {
-        free_mesh(c->pt);
-        return c->fail(RT_ERR_OOM, "host memory for a mesh of %u triangles", n_tris);
-    } catch (const std::system_error& e) {
-        free_mesh(c->pt);
-        return c->fail(RT_ERR_STATE, "BVH build: %s", e.what());
-    } catch (const std::exception& e) {
-        free_mesh(c->pt);
-        return c->fail(RT_ERR_INVALID, "BVH build: %s", e.what());
-    } catch (...) {
-        free_mesh(c->pt);
-        return c->fail(RT_ERR_INVALID, "BVH build failed");
+    return guarded(c, "mesh build", [&] { return set_mesh_impl(c, verts, albedo, emission, n_tris, options); });
+}
+
+int rt_mesh_chunk_info(rt_ctx* ctx, uint32_t chunk, uint32_t* count, uint32_t* tri_ids, uint32_t capacity) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return RT_ERR_INVALID;
+    if (!c->pt.host) return c->fail(RT_ERR_STATE, "not a two-level mesh");
+    const rt::TwoLevelBvh& tl = c->pt.host->tl;
+    if (chunk >= tl.blas.size()) return c->fail(RT_ERR_INVALID, "chunk %u of %zu", chunk, tl.blas.size());
+    const uint32_t first = tl.first[chunk], n = tl.first[chunk + 1] - first;
+    if (count) *count = n;
+    if (tri_ids) {
+        if (capacity < n) return c->fail(RT_ERR_INVALID, "tri_ids holds %u of %u triangles", capacity, n);
+        std::memcpy(tri_ids, &tl.sorted[first], (size_t)n * 4);
     }
+    return RT_OK;
+}
+
+int rt_update_mesh_chunk(rt_ctx* ctx, uint32_t chunk, const float* verts) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return RT_ERR_INVALID;
+    return guarded(c, "chunk rebuild", [&] { return update_chunk_impl(c, chunk, verts); });
 }
 
 int rt_render_pt(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, float* rgb_out) {

@@ -5,10 +5,12 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/rt_abi.h"
+#include "bvh_build.h"
 
 static_assert(sizeof(rt_material) == 32, "std140 Material stride");
 static_assert(sizeof(rt_object) == 16, "std140 Object stride");
@@ -166,7 +168,16 @@ struct PtFrame {
     float ray_eps;
 };
 
+struct MeshHost {  // host side of a two-level mesh: what rt_update_mesh_chunk needs to rebuild one chunk
+    TwoLevelBvh tl;
+    std::vector<float> v0, e1, e2;          // original triangle order
+    std::vector<float> albedo, emission;    // original triangle order, 3 floats each
+    std::vector<uint32_t> light_ids;        // emissive triangles, ascending
+};
+
 struct PtData {  // device residency of one mesh + the wavefront buffers
+    std::unique_ptr<MeshHost> host;  // two-level meshes only
+    size_t cap_nodes = 0;            // nodes d_nodes has room for
     bool borrowed_mesh = false;  // the mesh arrays belong to another context (frame-slot lanes share their parent's mesh)
     uint32_t n_tris = 0, n_nodes = 0, n_lights = 0, bvh_depth = 0;
     float bvh_build_ms = 0.0f, bvh_pad = 0.0f;

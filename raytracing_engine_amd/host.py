@@ -294,13 +294,29 @@ class Renderer:
         return s.as_dict()
 
     # ---- path B: triangle mesh + BVH + wavefront path tracer (no reference counterpart) ----------
-    def set_mesh(self, verts, albedo, emission):
+    def set_mesh(self, verts, albedo, emission, bvh_levels=1, blas_chunks=0):
+        """Upload a triangle mesh and build its BVH (rt_set_mesh / rt_set_mesh_ex).  bvh_levels=2: a top level over
+        blas_chunks (0 = 64) bottom-level chunks, flattened into the same node array; frames are identical."""
         verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 9)
         albedo = np.ascontiguousarray(albedo, np.float32).reshape(-1, 3)
         emission = np.ascontiguousarray(emission, np.float32).reshape(-1, 3)
         if not (len(verts) == len(albedo) == len(emission)):
             raise ValueError("verts/albedo/emission disagree on the triangle count")
-        self._check(self._lib.rt_set_mesh(self._ctx, _fptr(verts), _fptr(albedo), _fptr(emission), len(verts)))
+        opt = _lib.MeshOptions(bvh_levels, blas_chunks)
+        self._check(self._lib.rt_set_mesh_ex(self._ctx, _fptr(verts), _fptr(albedo), _fptr(emission), len(verts), C.byref(opt)))
+
+    def mesh_chunk(self, chunk):
+        """Original triangle indices of bottom-level chunk `chunk` of a two-level mesh, in rt_update_mesh_chunk's order."""
+        n = C.c_uint32()
+        self._check(self._lib.rt_mesh_chunk_info(self._ctx, chunk, C.byref(n), None, 0))
+        ids = np.empty(n.value, np.uint32)
+        self._check(self._lib.rt_mesh_chunk_info(self._ctx, chunk, None, ids.ctypes.data_as(C.POINTER(C.c_uint32)), n.value))
+        return ids
+
+    def update_mesh_chunk(self, chunk, verts):
+        """New vertices (count x 9, mesh_chunk order) for one chunk of a two-level mesh: only that chunk is rebuilt."""
+        verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 9)
+        self._check(self._lib.rt_update_mesh_chunk(self._ctx, chunk, _fptr(verts)))
 
     def pt_params(self, spp=4, bounces=1, seed=1, sky=(0.0, 0.0, 0.0), ray_eps=1e-3, count_traversal=False, max_paths=0, tune_refill_min=0,
                   tune_blocks_per_cu=0, tune_lds_stack=0, tune_no_overlap=0, tune_no_packet=0, tune_sort_rays=0):

@@ -8,7 +8,7 @@
 // No reference counterpart (the reference has no triangles or BVH).
 //
 //   bvh8_walk <in.bin> <out.bin>
-//   in : u32 n_tris, u32 n_rays, u32 any_hit, f32 verts[n_tris*9], f32 origins[n_rays*3], f32 dirs[n_rays*3]
+//   in : u32 n_tris, u32 n_rays, u32 any_hit | chunks << 8 (chunks > 0: two-level build), f32 verts[n_tris*9], f32 origins[n_rays*3], f32 dirs[n_rays*3]
 //   out: per ray  u32 nodes, u32 tris, f32 t (closest: distance or inf; any: 1/0), i32 tri (id or -1; any: 1/0)
 #include <cmath>
 #include <cstdint>
@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     if (!f) return 2;
     uint32_t hdr[3];
     if (std::fread(hdr, 4, 3, f) != 3) return 2;
-    const uint32_t n = hdr[0], n_rays = hdr[1], any_hit = hdr[2];
+    const uint32_t n = hdr[0], n_rays = hdr[1], any_hit = hdr[2] & 0xffu, chunks = hdr[2] >> 8;  // chunks > 0: two-level build
     std::vector<float> verts((size_t)n * 9), org((size_t)n_rays * 3), dir((size_t)n_rays * 3);
     if (std::fread(verts.data(), 4, verts.size(), f) != verts.size() || std::fread(org.data(), 4, org.size(), f) != org.size() ||
         std::fread(dir.data(), 4, dir.size(), f) != dir.size())
@@ -74,7 +74,10 @@ int main(int argc, char** argv) {
             e2[3 * i + a] = verts[9 * i + 6 + a] - verts[9 * i + a];
         }
     rt::BvhResult bvh;
-    if (!rt::build_bvh(v0.data(), e1.data(), e2.data(), n, rt::kBvhMaxDepth, &bvh)) return 3;
+    rt::TwoLevelBvh tl;
+    if (chunks ? !rt::build_bvh_two_level(v0.data(), e1.data(), e2.data(), n, chunks, rt::kBvhMaxDepth, &tl, &bvh)
+               : !rt::build_bvh(v0.data(), e1.data(), e2.data(), n, rt::kBvhMaxDepth, &bvh))
+        return 3;
     std::vector<Tri> tris(n);
     for (size_t li = 0; li < n; li++) {
         const uint32_t t = bvh.order[li];

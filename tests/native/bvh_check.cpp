@@ -1,6 +1,6 @@
 // bvh_check.cpp — host-side structural check of the compressed 8-wide BVH (csrc/bvh_build.cpp),
 // built with -fsanitize=address,undefined by tests/test_bvh_build_host.py.  No GPU involved.
-//   bvh_check <n_tris> <seed> <edge>
+//   bvh_check <n_tris> <seed> <edge> [chunks [chunk-to-rebuild]]
 // Verifies: the leaf order is a permutation; every triangle is reachable exactly once; inner-child
 // indexing (child_base + popcount(imask below slot)) and leaf indexing (one triangle per leaf slot, tri_base +
 // popcount(leafmask below slot)) are consistent; empty slots hold inverted boxes; every leaf triangle lies inside its de-quantised child box; depth <= stack_need - 1.
@@ -34,8 +34,18 @@ int main(int argc, char** argv) {
         for (int a = 0; a < 3; a++) e1[3 * 5 + a] = e2[3 * 5 + a] = 0.0f;
         for (int a = 0; a < 3; a++) { v0[3 * 7 + a] = v0[3 * 6 + a]; e1[3 * 7 + a] = e1[3 * 6 + a]; e2[3 * 7 + a] = e2[3 * 6 + a]; }
     }
+    const uint32_t chunks = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 0;  // > 0: two-level build (top level over `chunks` bottom-level BVHs, flattened)
     rt::BvhResult b;
-    if (!rt::build_bvh(v0.data(), e1.data(), e2.data(), n, rt::kBvhMaxDepth, &b)) { std::puts("FAIL build"); return 1; }
+    rt::TwoLevelBvh tl;
+    if (chunks) {
+        if (!rt::build_bvh_two_level(v0.data(), e1.data(), e2.data(), n, chunks, rt::kBvhMaxDepth, &tl, &b)) { std::puts("FAIL two-level build"); return 1; }
+        if (argc > 5) {  // rebuild one chunk after moving its triangles: the flattened result must pass the same checks
+            const uint32_t c = (uint32_t)std::atoi(argv[5]) % (uint32_t)tl.blas.size();
+            for (uint32_t i = tl.first[c]; i < tl.first[c + 1]; i++)
+                for (int a = 0; a < 3; a++) v0[3 * (size_t)tl.sorted[i] + a] = v0[3 * (size_t)tl.sorted[i] + a] * 0.5f + 0.25f;
+            if (!rt::rebuild_chunk(v0.data(), e1.data(), e2.data(), n, c, rt::kBvhMaxDepth, &tl, &b)) { std::puts("FAIL chunk rebuild"); return 1; }
+        }
+    } else if (!rt::build_bvh(v0.data(), e1.data(), e2.data(), n, rt::kBvhMaxDepth, &b)) { std::puts("FAIL build"); return 1; }
     if (b.order.size() != n || b.nodes.size() != (size_t)b.n_nodes * 20) { std::puts("FAIL sizes"); return 1; }
     std::vector<uint8_t> seen(n, 0);
     for (uint32_t t : b.order) {

@@ -281,7 +281,8 @@ def walker(tmp_path_factory):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path_factory.mktemp("walk") / "bvh8_walk"
     subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-ffp-contract=off", "-fno-fast-math", os.path.join(root, "tests", "native", "bvh8_walk.cpp"),
-                    os.path.join(root, "raytracing_engine_amd", "csrc", "bvh_build.cpp"), "-o", str(exe)], check=True)
+                    os.path.join(root, "raytracing_engine_amd", "csrc", "bvh_build.cpp"), os.path.join(root, "raytracing_engine_amd", "csrc", "bvh_two_level.cpp"),
+                    "-o", str(exe)], check=True)
     return str(exe)
 
 
@@ -325,3 +326,75 @@ def test_traversal_counts_match_the_host_walk_of_the_same_bvh(renderer, walker, 
         assert np.array_equal(rec["nodes"], counts[:, 0]), f"node fetches differ for {np.count_nonzero(rec['nodes'] != counts[:, 0])} rays"
         assert np.array_equal(rec["tris"], counts[:, 1]), f"triangle tests differ for {np.count_nonzero(rec['tris'] != counts[:, 1])} rays"
         assert counts[:, 0].min() >= 1 and (n_tris == 38 or counts[:, 0].sum() > 3 * n)
+
+
+def test_two_level_bvh_frames_counts_and_chunk_rebuild(renderer, walker, tmp_path):
+    """BASELINE.json configs[2] names a "2-level BVH": rt_set_mesh_ex(bvh_levels = 2) builds a top level over 64
+    bottom-level chunks and flattens both into the node array the kernels walk.  The frame must be the oracle's (and
+    therefore the single-level frame), the host walker must reproduce the per-ray traversal counts on ITS two-level
+    build, and after rt_update_mesh_chunk moved one chunk's triangles the frame must be the oracle's for the moved mesh."""
+    import subprocess
+
+    v, a, e = scenes.soup_scene(30000, seed=14, edge=0.6)
+    kw = dict(spp=2, bounces=2, seed=11, sky=(0.2, 0.2, 0.25))
+    renderer.resize(128, 80)
+    renderer.set_mesh(v, a, e)
+    one = renderer.render_pt(**kw)
+    renderer.set_mesh(v, a, e, bvh_levels=2, blas_chunks=64)
+    st = renderer.pt_stats()
+    assert st["bvh_levels"] == 2 and st["blas_chunks"] == 64 and st["tlas_nodes"] >= 9 and st["n_nodes"] > st["tlas_nodes"]
+    two = renderer.render_pt(**kw)
+    ref, ct = O.TriScene(v, a, e).render(128, 80, **kw)
+    st = renderer.pt_stats()
+    assert np.array_equal(two, ref) and np.array_equal(one, two) and st["stack_overflow"] == 0
+    assert (st["camera_rays"], st["bounce_rays"], st["shadow_rays"]) == (ct["camera_rays"], ct["bounce_rays"], ct["shadow_rays"])
+    # traversal counts of the flattened two-level tree against the host walk of the same build
+    rng = np.random.default_rng(5)
+    n = 3000
+    o = rng.uniform([-12, 0, -12], [12, 30, 12], size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    t, tri, counts = renderer.trace_rays(o, d, counted=True)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(np.array([len(v), n, 0 | (64 << 8)], np.uint32).tobytes())
+        f.write(np.ascontiguousarray(v, np.float32).tobytes())
+        f.write(o.tobytes())
+        f.write(d.tobytes())
+    subprocess.run([walker, str(fin), str(fout)], check=True)
+    rec = np.fromfile(fout, dtype=np.dtype([("nodes", "<u4"), ("tris", "<u4"), ("t", "<f4"), ("tri", "<i4")]))
+    assert np.array_equal(rec["tri"], tri) and np.array_equal(rec["t"], t)
+    assert np.array_equal(rec["nodes"], counts[:, 0]) and np.array_equal(rec["tris"], counts[:, 1])
+    # move the triangles of one chunk (the light's chunk too, so the light list has to follow) and rebuild only it
+    light_chunk = next(c for c in range(64) if (len(v) - 1) in renderer.mesh_chunk(c))
+    v2 = v.copy()
+    for chunk in (5, light_chunk):
+        ids = renderer.mesh_chunk(chunk)
+        assert len(ids) in (len(v) // 64, len(v) // 64 + 1) and len(np.unique(ids)) == len(ids)
+        v2[ids] += np.tile(np.array([0.4, -0.3, 0.2], np.float32), 3)
+        renderer.update_mesh_chunk(chunk, v2[ids])
+    st = renderer.pt_stats()
+    assert st["ms_build_blas"] > 0 and st["bvh_build_ms"] >= st["ms_build_blas"]
+    moved = renderer.render_pt(**kw)
+    ref2, ct2 = O.TriScene(v2, a, e).render(128, 80, **kw)
+    st = renderer.pt_stats()
+    assert np.array_equal(moved, ref2) and not np.array_equal(moved, two)
+    assert (st["camera_rays"], st["bounce_rays"], st["shadow_rays"]) == (ct2["camera_rays"], ct2["bounce_rays"], ct2["shadow_rays"])
+    renderer.set_mesh(v2, a, e, bvh_levels=2)
+    assert np.array_equal(renderer.render_pt(**kw), ref2)
+    # error behaviour: no such chunk; vertices leaving the range the padding was chosen for (the mesh stays as it was); single-level mesh
+    with pytest.raises(R.RtError) as ei:
+        renderer.update_mesh_chunk(64, v2[:10])
+    assert ei.value.code == -1
+    ids = renderer.mesh_chunk(0)
+    with pytest.raises(R.RtError) as ei:
+        renderer.update_mesh_chunk(0, v2[ids] * 100.0)
+    assert ei.value.code == -1
+    assert np.array_equal(renderer.render_pt(**kw), ref2)
+    renderer.set_mesh(v, a, e)
+    with pytest.raises(R.RtError) as ei:
+        renderer.update_mesh_chunk(0, v[:10])
+    assert ei.value.code == -4
+    with pytest.raises(R.RtError):
+        renderer.set_mesh(v, a, e, bvh_levels=3)
+    renderer.resize(64, 64)
