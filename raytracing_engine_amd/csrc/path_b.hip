@@ -383,6 +383,14 @@ __device__ __forceinline__ uint32_t ray_sort_key(const float4* __restrict__ node
     return (oct << 6) | (uz << 4) | (uy << 2) | ux;
 }
 
+// camera ray of sample s of pixel (px, py): fragment.glsl:129-133 with the pixel-centre 0.5 replaced by a random offset
+__device__ __forceinline__ v3 camera_dir(const PtFrame& f, uint32_t px, uint32_t py, uint32_t s) {
+    const uint32_t key = path_key(py * f.width + px, s, f.seed);
+    const float nx = ((((float)px + rnd(key, 0, 0)) * 2.0f) / (float)f.width - 1.0f) * f.cam.ratio[0];
+    const float ny = ((((float)py + rnd(key, 0, 1)) * 2.0f) / (float)f.height - 1.0f) * f.cam.ratio[1];
+    return normalize(rotate_q(f.cam.rot[0], f.cam.rot[1], f.cam.rot[2], f.cam.rot[3], mk(nx, 1.0f, ny)));
+}
+
 // ---- generate -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, PtState st, uint32_t* __restrict__ queue, uint32_t* __restrict__ ctr) {
     __shared__ uint32_t lds[32];
@@ -393,11 +401,7 @@ __global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, P
         uint32_t px, py, lx, ly, k;
         if (slot_pixel(f, slot, px, py, lx, ly, k)) {
             alive = true;
-            const uint32_t key = path_key(py * f.width + px, s, f.seed);
-            // camera ray: fragment.glsl:129-133 with the pixel-centre 0.5 replaced by a random offset
-            const float nx = ((((float)px + rnd(key, 0, 0)) * 2.0f) / (float)f.width - 1.0f) * f.cam.ratio[0];
-            const float ny = ((((float)py + rnd(key, 0, 1)) * 2.0f) / (float)f.height - 1.0f) * f.cam.ratio[1];
-            const v3 d = normalize(rotate_q(f.cam.rot[0], f.cam.rot[1], f.cam.rot[2], f.cam.rot[3], mk(nx, 1.0f, ny)));
+            const v3 d = camera_dir(f, px, py, s);
             st.ray_o[pid] = make_float4(f.cam.pos[0], f.cam.pos[1], f.cam.pos[2], 0.0f);
             st.ray_d[pid] = make_float4(d.x, d.y, d.z, 0.0f);
             st.thr[pid] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
@@ -582,6 +586,7 @@ constexpr int kPkStack = 40;  // >= kBvhMaxDepth + 2 groups: one pending sibling
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const PtFrame f, PtState st, unsigned long long* __restrict__ stats) {
+    // (PtState is passed by value: its pointers are written through)
     __shared__ float s_planes[4][64];
     __shared__ unsigned long long s_stack[4][kPkStack];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -591,12 +596,13 @@ __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const P
 
     bool alive = false;
     v3 d = mk(0.0f, 1.0f, 0.0f);
-    if (pid < f.n_paths) {
+    if (pid < f.n_paths) {  // the generate stage, fused: this kernel makes the camera rays it traces (pt_shade(0) needs only the direction)
+        const uint32_t slot = pid / f.spp_batch;
         uint32_t px, py, lx, ly, k;
-        alive = slot_pixel(f, pid / f.spp_batch, px, py, lx, ly, k);
+        alive = slot_pixel(f, slot, px, py, lx, ly, k);
         if (alive) {
-            const float4 rd = st.ray_d[pid];
-            d = mk(rd.x, rd.y, rd.z);
+            d = camera_dir(f, px, py, f.sample0 + (pid - slot * f.spp_batch));
+            st.ray_d[pid] = make_float4(d.x, d.y, d.z, 0.0f);
         }
     }
     const v3 o = mk(f.cam.pos[0], f.cam.pos[1], f.cam.pos[2]);  // wave-uniform
@@ -706,7 +712,10 @@ __global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, con
                                                            const uint32_t* __restrict__ count_ptr, uint32_t depth, uint32_t* __restrict__ next_queue,
                                                            uint32_t* __restrict__ next_ctr, uint32_t sort_rays) {
     __shared__ uint32_t lds[kSortBins + 40];
-    const uint32_t n = *count_ptr;
+    // queue == nullptr (depth 0 behind the packet kernel, which has no generate stage and no queue): the items are the
+    // path ids themselves; origin = camera, throughput 1, radiance 0 are known and not read from the path state
+    const bool direct = queue == nullptr;
+    const uint32_t n = direct ? f.n_paths : *count_ptr;
     const uint32_t stride = gridDim.x * kAppendThreads;
     // grid-stride over whole workgroups: the trip count is workgroup-uniform (barriers in block_append)
     for (uint32_t base = blockIdx.x * kAppendThreads; base < n; base += stride) {
@@ -714,13 +723,21 @@ __global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, con
         bool bounce = false, shadow = false;
         uint32_t pid = 0;
         float4 so = {}, sd = {}, scn = {};
-        if (i < n) {
-            pid = queue[i];
+        bool item = i < n;
+        if (item && direct) {
+            uint32_t px, py, lx, ly, k;
+            item = slot_pixel(f, i / f.spp_batch, px, py, lx, ly, k);
+        }
+        if (item) {
+            pid = direct ? i : queue[i];
             const float2 hrec = st.hit[pid];
             const int li = __float_as_int(hrec.y);
-            const float4 ro = st.ray_o[pid], rd = st.ray_d[pid], T = st.thr[pid];
+            const float4 rd = st.ray_d[pid];
+            const float4 ro = direct ? make_float4(f.cam.pos[0], f.cam.pos[1], f.cam.pos[2], 0.0f) : st.ray_o[pid];
+            const float4 T = direct ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : st.thr[pid];
             const v3 o = mk(ro.x, ro.y, ro.z), d = mk(rd.x, rd.y, rd.z);
-            float4 L = st.rad[pid];
+            float4 L = direct ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : st.rad[pid];
+            if (direct) st.rad[pid] = L;  // the shadow stage and pt_resolve read it; the branches below overwrite it where they add light
             if (li < 0) {  // left the scene
                 L.x = __builtin_fmaf(T.x, f.sky[0], L.x);
                 L.y = __builtin_fmaf(T.y, f.sky[1], L.y);

@@ -103,7 +103,9 @@ int ensure_levels(Ctx* c, uint32_t batch) {
     c->frame_valid = false;
     for (uint32_t i = 0; i < c->level_count; i++) {
         const size_t bytes = (size_t)c->dims[i][0] * c->dims[i][1] * sizeof(float) * batch;
-        if (hipMalloc((void**)&c->d_level[i], bytes) != hipSuccess || hipMemset(c->d_level[i], 0, bytes) != hipSuccess)
+        // zero-filled ON THE CONTEXT'S STREAM: its streams are non-blocking, so a hipMemset on the null stream (asynchronous
+        // to the host for device memory) would not be ordered before the level kernels that follow and could wipe their output
+        if (hipMalloc((void**)&c->d_level[i], bytes) != hipSuccess || hipMemsetAsync(c->d_level[i], 0, bytes, c->stream) != hipSuccess)
             return c->fail(RT_ERR_OOM, "pyramid level %u x %u samples (%zu bytes)", i, batch, bytes);
     }
     c->level_batch = batch;

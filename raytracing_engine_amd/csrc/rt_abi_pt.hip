@@ -260,9 +260,12 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
 
         const size_t ctr_words = (size_t)rt::PT_CTR_STRIDE * (prm->bounces + 2);
         RT_HIP(c, hipMemsetAsync(pt.d_ctr, 0, ctr_words * sizeof(uint32_t), c->stream));
-        tm.begin(0);
-        if (int rc = rt::launch_pt_generate(c, f, pt.st, pt.d_queue[0], pt.d_ctr)) return rc;
-        tm.end();
+        const bool packet = !prm->tune_no_packet;  // camera rays through the packet kernel, which makes its own rays: no generate stage, no queue 0
+        if (!packet) {
+            tm.begin(0);
+            if (int rc = rt::launch_pt_generate(c, f, pt.st, pt.d_queue[0], pt.d_ctr)) return rc;
+            tm.end();
+        }
         bool shadow_deferred = false;  // fused mode: shadow(d - 1) waits for the launch of closest(d)
         for (uint32_t d = 0; d <= prm->bounces; d++) {
             uint32_t* ctr_d = pt.d_ctr + (size_t)rt::PT_CTR_STRIDE * d;
@@ -270,7 +273,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             const uint32_t* q = pt.d_queue[d & 1];
             uint32_t* qn = pt.d_queue[(d + 1) & 1];
             tm.begin(1);
-            if (d == 0 && !prm->tune_no_packet) {  // camera rays: one shared origin, coherent 4x4-pixel blocks per wave
+            if (d == 0 && packet) {  // camera rays: one shared origin, coherent 4x4-pixel blocks per wave
                 if (int rc = rt::launch_pt_trace_packet(c, sc, f, pt.st, pt.d_stats, count)) return rc;
             } else if (shadow_deferred) {  // closest(d) + shadow(d - 1): ctr_d holds both the closest count of depth d and the shadow count of depth d - 1
                 if (int rc = rt::launch_pt_trace_fused(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, ctr_d + rt::PT_CTR_SHADOW_COUNT,
@@ -288,7 +291,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
                 shadow_pending = false;
             }
             tm.begin(2);
-            if (int rc = rt::launch_pt_shade(c, sc, f, pt.st, q, ctr_d + rt::PT_CTR_COUNT, d, qn, ctr_n, grid_stride, prm->tune_sort_rays != 0)) return rc;
+            if (int rc = rt::launch_pt_shade(c, sc, f, pt.st, d == 0 && packet ? nullptr : q, ctr_d + rt::PT_CTR_COUNT, d, qn, ctr_n, grid_stride, prm->tune_sort_rays != 0)) return rc;
             tm.end();
             if (pt.n_lights) {
                 if (fused && d < prm->bounces) {  // goes into the same launch as closest(d + 1)
@@ -328,7 +331,16 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         if (sync) {  // ray counters of this batch (the copy is ordered after the kernels on the stream)
             RT_HIP(c, hipMemcpyAsync(h_ctr.data(), pt.d_ctr, ctr_words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             RT_HIP(c, hipStreamSynchronize(c->stream));
-            cam += h_ctr[rt::PT_CTR_COUNT];
+            if (packet) {  // no queue 0: camera rays = samples of the owned pixels inside the frame
+                uint64_t px_owned = 0;
+                for (uint32_t t = c->part.rank; t < c->part.tiles_x * c->part.tiles_y; t += c->part.n_ranks) {
+                    const uint32_t ty = t / c->part.tiles_x, tx = t % c->part.tiles_x;
+                    px_owned += (uint64_t)std::min<uint32_t>(RT_TILE, c->width - tx * RT_TILE) * std::min<uint32_t>(RT_TILE, c->height - ty * RT_TILE);
+                }
+                cam += px_owned * nb;
+            } else {
+                cam += h_ctr[rt::PT_CTR_COUNT];
+            }
             for (uint32_t d = 1; d <= prm->bounces + 1; d++) {
                 if (d <= prm->bounces) bnc += h_ctr[(size_t)rt::PT_CTR_STRIDE * d + rt::PT_CTR_COUNT];
                 shd += h_ctr[(size_t)rt::PT_CTR_STRIDE * d + rt::PT_CTR_SHADOW_COUNT];
@@ -537,6 +549,7 @@ int set_mesh_impl(Ctx* c, const float* verts, const float* albedo, const float* 
     RT_HIP(c, hipMemcpy(pt.d_albedo, alb.data(), n * 16, hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(pt.d_emission, emi.data(), n * 16, hipMemcpyHostToDevice));
     if (!lights.empty()) RT_HIP(c, hipMemcpy(pt.d_lights, lights.data(), lights.size() * 4, hipMemcpyHostToDevice));
+    RT_HIP(c, hipDeviceSynchronize());  // the uploads ran on the null stream; the context's streams are non-blocking and do not wait for it
     pt.n_tris = n_tris;
     pt.n_lights = (uint32_t)lights.size();
     pt.stats = rt_pt_stats{};
@@ -630,6 +643,7 @@ int update_chunk_impl(Ctx* c, uint32_t chunk, const float* verts) {
             RT_HIP(c, hipMemcpy(pt.d_lights, leaf_of.data(), leaf_of.size() * 4, hipMemcpyHostToDevice));
         }
     }
+    RT_HIP(c, hipDeviceSynchronize());  // null-stream uploads before anything on the context's non-blocking streams
     pt.stats.ms_build_blas = (float)h.tl.ms_blas;
     pt.stats.ms_build_tlas = (float)h.tl.ms_tlas;
     pt.stats.ms_build_flatten = (float)h.tl.ms_flatten;
