@@ -245,6 +245,17 @@ def stub_main(args, rank, world):
         dist.destroy_process_group()
 
 
+def tune_from_env():
+    """RT_BENCH_TUNE="tune_no_packet=1,tune_sort_rays=1": tuning knobs of rt_pt_params for A/B profiles (tools/refresh_profiles.sh);
+    unset for every measurement that is reported."""
+    out = {}
+    for item in os.environ.get("RT_BENCH_TUNE", "").split(","):
+        if "=" in item:
+            k, v = item.split("=", 1)
+            out[k.strip()] = int(v)
+    return out
+
+
 # ---- workloads -----------------------------------------------------------------------------
 class SpheresWorkload:
     """BASELINE.json configs[1]: the 8-sphere Cornell-style scene, 1920x1080, 4 spp, path A
@@ -382,7 +393,7 @@ class TriWorkload:
     width, height, spp, bounces, seed = 1920, 1080, 4, 1, 1
     sky = (0.2, 0.2, 0.25)
     dtype = "f32"
-    dominant_kernel = "pt_trace<false, false>"
+    dominant_kernel = "pt_trace_packet"
 
     def __init__(self, R, renderer):
         self.R, self.r = R, renderer
@@ -391,13 +402,15 @@ class TriWorkload:
         self.pos = np.zeros(3, np.float32)
         renderer.set_mesh(*self.mesh)
         renderer.resize(self.width, self.height)
-        self.params = renderer.pt_params(spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky)
+        self.params = renderer.pt_params(spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky, **tune_from_env())
 
     def describe(self):
         st = self.r.pt_stats()
-        return {"workload": f"{self.name}: {self.n_tris} random triangles (edge +-{self.edge}) + 1 emissive quad, compressed BVH8 "
-                            f"({st['n_nodes']} nodes, depth {st['bvh_depth']}), {self.width}x{self.height}, {self.spp} spp, "
-                            f"{self.bounces} bounce + NEE, path B wavefront path tracer",
+        tune = tune_from_env()
+        return {"workload": f"{self.name}: {self.n_tris} random triangles (edge +-{self.edge}) + 1 emissive quad, single-level compressed BVH8 "
+                            f"({st['n_nodes']} nodes, depth {st['bvh_depth']}, one-triangle leaves), {self.width}x{self.height}, {self.spp} spp, "
+                            f"{self.bounces} bounce + NEE, path B wavefront path tracer (camera rays: packet kernel)"
+                            + (f" [RT_BENCH_TUNE: {tune}]" if tune else ""),
                 "width": self.width, "height": self.height, "spp": self.spp, "bounces": self.bounces, "tile": 64,
                 "bvh_build_ms_host": round(st["bvh_build_ms"], 1)}
 
@@ -425,20 +438,26 @@ class TriWorkload:
         return None
 
     def roofline(self):
-        """Dominant kernel = pt_trace<closest>.  Algorithmic bytes per launch: every compressed
-        8-wide node fetched = 80 B, every triangle tested = 48 B, per ray 32 B ray read + 8 B hit write + 4 B queue
-        entry.  The node / triangle counts come from the kernel's COUNT instantiation; that they are what a walk of
-        the same tree produces is checked per ray by tests/test_gpu_path_b.py (host walker tests/native/bvh8_walk.cpp).
-        Beside them: oracle B's counts on its own BVH2 with SURVEY.md section 8d's per-ray formula."""
+        """The step's three traversal kernels in the default schedule, timed with HIP events around every launch
+        (profile_stages): pt_trace_packet (camera rays, wave-uniform), pt_trace_fused (closest-hit rays of depth 1 + the
+        shadow rays of depth 0 in one persistent launch) and the last pt_trace<any>.  The dominant one - the fused launch -
+        carries the roofline.  Algorithmic bytes: every BVH8 node record fetched = 80 B, every
+        triangle record = 48 B, per ray its state (44 B closest: 32 B ray, 8 B hit, 4 B queue entry; 48 B shadow); the
+        per-lane kernels fetch a record once per ray, the packet kernel once per wave of 64 camera rays.  The counts come
+        from the kernels' COUNT instantiations; that they are what a walk of the same tree produces is checked per ray
+        by tests/test_gpu_path_b.py (host walker tests/native/bvh8_walk.cpp).  Beside them: oracle B's counts on its own
+        BVH2 with SURVEY.md section 8d's per-ray formula."""
         r = self.r
-        prm = r.pt_params(spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky, count_traversal=True)
+        tune = tune_from_env()
+        prm = r.pt_params(spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky, count_traversal=True, **tune)
         r.render_pt(self.rot, self.pos, params=prm)
         ct = r.pt_stats()
         cfg = r.default_config()
         cfg.profile_stages = 1
         r.set_config(cfg)
         reps = 5
-        acc = {k: 0.0 for k in ("ms_generate", "ms_trace_closest", "ms_shade", "ms_trace_shadow", "ms_resolve", "ms_total")}
+        keys = ("ms_generate", "ms_trace_packet", "ms_trace_closest", "ms_trace_fused", "ms_shade", "ms_trace_shadow", "ms_resolve", "ms_total")
+        acc = {k: 0.0 for k in keys}
         for _ in range(reps):
             r.render_pt(self.rot, self.pos, params=self.params)
             st = r.pt_stats()
@@ -446,32 +465,56 @@ class TriWorkload:
                 acc[k] += st[k] / reps
         cfg.profile_stages = 0
         r.set_config(cfg)
-        closest_rays = ct["camera_rays"] + ct["bounce_rays"]
-        all_rays = closest_rays + ct["shadow_rays"]
-        bytes_closest = ct["nodes_visited"] * 80.0 + ct["tris_tested"] * 48.0 + closest_rays * 44.0
-        bytes_shadow = ct["shadow_nodes_visited"] * 80.0 + ct["shadow_tris_tested"] * 48.0 + ct["shadow_rays"] * 48.0
-        n_launch = st["launches_trace_closest"]
-        ms = acc["ms_trace_closest"] / n_launch
-        l1_tbs = bytes_closest / (acc["ms_trace_closest"] * 1e-3) / 1e12
-        out = {"kernel": "pt_trace<closest>", "avg_kernel_ms": round(ms, 4), "launches_per_step": n_launch,
-               "algorithmic_bytes_per_launch": bytes_closest / n_launch,
-               "algorithmic_definition": "80 B per BVH8 node fetched + 48 B per triangle tested + 44 B per ray (32 B ray, 8 B hit, 4 B queue entry), "
-                                         "every fetch charged as if it came from HBM",
+        all_rays = ct["camera_rays"] + ct["bounce_rays"] + ct["shadow_rays"]
+        fused_on = st["launches_trace_fused"] > 0
+        # bytes each kernel moves through the cache hierarchy
+        b_packet = ct["packet_nodes_fetched"] * 80.0 + ct["packet_tris_fetched"] * 48.0 + ct["camera_rays"] * 24.0  # 16 B direction written + 8 B hit
+        b_closest = ct["nodes_visited"] * 80.0 + ct["tris_tested"] * 48.0 + (ct["bounce_rays"] if ct["packets"] else ct["bounce_rays"] + ct["camera_rays"]) * 44.0
+        b_shadow_fused = ct["fused_shadow_nodes"] * 80.0 + ct["fused_shadow_tris"] * 48.0 + ct["fused_shadow_rays"] * 48.0
+        b_shadow_alone = (ct["shadow_nodes_visited"] - ct["fused_shadow_nodes"]) * 80.0 + (ct["shadow_tris_tested"] - ct["fused_shadow_tris"]) * 48.0 \
+            + (ct["shadow_rays"] - ct["fused_shadow_rays"]) * 48.0
+        kernels = {}
+        if ct["packets"]:
+            kernels["pt_trace_packet"] = {"ms": acc["ms_trace_packet"], "launches": 1, "bytes": b_packet, "rays": ct["camera_rays"]}
+        if fused_on:
+            kernels["pt_trace_fused"] = {"ms": acc["ms_trace_fused"], "launches": st["launches_trace_fused"], "bytes": b_closest + b_shadow_fused,
+                                         "rays": ct["bounce_rays"] + ct["fused_shadow_rays"]}
+        else:
+            kernels["pt_trace<closest>"] = {"ms": acc["ms_trace_closest"], "launches": st["launches_trace_closest"] - (1 if ct["packets"] else 0), "bytes": b_closest,
+                                            "rays": ct["bounce_rays"] if ct["packets"] else ct["bounce_rays"] + ct["camera_rays"]}
+        kernels["pt_trace<any>"] = {"ms": acc["ms_trace_shadow"], "launches": st["launches_trace_shadow"] - st["launches_trace_fused"], "bytes": b_shadow_alone,
+                                    "rays": ct["shadow_rays"] - ct["fused_shadow_rays"]}
+        name = max(kernels, key=lambda k: kernels[k]["ms"])
+        dom = kernels[name]
+        self.dominant_kernel = {"pt_trace_fused": "pt_trace_fused", "pt_trace_packet": "pt_trace_packet", "pt_trace<closest>": "pt_trace<false, false>",
+                                "pt_trace<any>": "pt_trace<true, false>"}[name]
+        n_launch = max(dom["launches"], 1)
+        ms = dom["ms"] / n_launch
+        l1_tbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e12
+        lane_nodes = ct["nodes_visited"] + ct["shadow_nodes_visited"]
+        lane_rays = ct["bounce_rays"] + ct["shadow_rays"] + (0 if ct["packets"] else ct["camera_rays"])
+        out = {"kernel": name, "avg_kernel_ms": round(ms, 4), "launches_per_step": n_launch,
+               "algorithmic_bytes_per_launch": dom["bytes"] / n_launch,
+               "algorithmic_definition": "80 B per BVH8 node record fetched + 48 B per triangle record fetched + per-ray state (44 B closest-hit: 32 B ray, 8 B hit, "
+                                         "4 B queue entry; 48 B shadow), every fetch charged as if it came from HBM",
+               "kernels": {k: {"ms_per_step": round(v["ms"], 4), "launches_per_step": v["launches"], "rays_per_step": int(v["rays"]),
+                               "algorithmic_GB_per_step": round(v["bytes"] / 1e9, 3), "algorithmic_GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                               "Mrays_per_s": round(v["rays"] / max(v["ms"], 1e-9) / 1e3, 1)} for k, v in kernels.items()},
                "gather_ceiling": {"achieved_TBps": round(l1_tbs, 2), "l2_resident_TBps": GATHER_CEILING_L2_TBS, "infinity_cache_TBps": GATHER_CEILING_IC_TBS,
                                   "over_l2_resident": round(l1_tbs / GATHER_CEILING_L2_TBS, 3), "over_infinity_cache": round(l1_tbs / GATHER_CEILING_IC_TBS, 3),
-                                  "definition": "bytes the traversal moves through the vector L1s (the algorithmic bytes) per second, against the gather "
+                                  "definition": "bytes the dominant kernel moves through the vector L1s (its algorithmic bytes) per second, against the gather "
                                                 "throughput tools/l1_gather_bench.hip measures for 80-byte records when the table fits one XCD's L2 and "
-                                                "when it is served from the Infinity Cache; the 18 MB node array + 48 MB of triangles sit between the two"},
-               "per_ray": {"nodes": round(ct["nodes_visited"] / closest_rays, 2), "tris": round(ct["tris_tested"] / closest_rays, 2),
-                           "bytes": round(bytes_closest / closest_rays, 1),
-                           "shadow_nodes": round(ct["shadow_nodes_visited"] / max(ct["shadow_rays"], 1), 2),
-                           "shadow_bytes": round(bytes_shadow / max(ct["shadow_rays"], 1), 1),
-                           "counted_by": "the kernel's COUNT instantiation on its BVH8; cross-checked per ray against a host walk of the same tree "
-                                         "(tests/test_gpu_path_b.py::test_traversal_counts_match_the_host_walk_of_the_same_bvh)"},
+                                                "when it is served from the Infinity Cache (profiles/r02_l1_gather_bench.txt); the 20 MB node array + 48 MB "
+                                                "of triangles sit between the two"},
+               "per_ray": {"per_lane_kernels": {"nodes": round(lane_nodes / max(lane_rays, 1), 2),
+                                                "tris": round((ct["tris_tested"] + ct["shadow_tris_tested"]) / max(lane_rays, 1), 2)},
+                           "packet_kernel": {"nodes_per_wave": round(ct["packet_nodes_fetched"] / max(ct["packets"], 1), 1),
+                                             "tris_per_wave": round(ct["packet_tris_fetched"] / max(ct["packets"], 1), 1), "waves": ct["packets"]},
+                           "counted_by": "the kernels' COUNT instantiations on their BVH8; the per-lane step functions are cross-checked per ray against a host "
+                                         "walk of the same tree (tests/test_gpu_path_b.py::test_traversal_counts_match_the_host_walk_of_the_same_bvh)"},
                "stage_ms": {k: round(v, 4) for k, v in acc.items()},
-               "shadow_kernel_GBs": round(bytes_shadow / max(acc["ms_trace_shadow"], 1e-9) / 1e6, 1),
-               "note": "the 66 MB scene is cache resident (L1 hit rate 84 %, L2 79 %), so HBM is not what binds this kernel: VALU issue and the "
-                       "vector L1's access rate do (DESIGN.md section 8)"}
+               "note": "the 70 MB scene is cache resident (round-1 counters: L1 hit rate 84 %, L2 79 %), so HBM is not what binds these kernels: vector-"
+                       "instruction issue and the vector L1's access rate do (DESIGN.md section 8)"}
         pin = self._pinned()
         if pin:  # N_node / N_tri counted by oracle B's instrumented traversal (its own BVH2, <= 4-triangle leaves), all rays
             n_rays = pin["camera_rays"] + pin["bounce_rays"] + pin["shadow_rays"]
@@ -532,7 +575,7 @@ class TerrainWorkload(TriWorkload):
         self.sky = (0.4, 0.5, 0.7)
         renderer.set_mesh(*self.mesh)
         renderer.resize(self.width, self.height)
-        self.params = renderer.pt_params(spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky)
+        self.params = renderer.pt_params(spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky, **tune_from_env())
 
     def describe(self):
         d = super().describe()

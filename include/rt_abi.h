@@ -241,15 +241,18 @@ typedef struct rt_pt_stats {
     float bvh_build_ms;
     uint32_t stack_overflow;   /* must be 0: traversal stack never exceeded */
     uint64_t camera_rays, bounce_rays, shadow_rays; /* last render: rays handed to BVH traversal */
-    uint64_t nodes_visited, tris_tested;            /* closest-hit launches: BVH node records fetched / triangle records fetched and tested;
-                                                       last render, count_traversal = 1 only.  The packet kernel fetches a record once per
-                                                       wave (64 camera rays), the per-lane kernel once per ray */
+    uint64_t nodes_visited, tris_tested;            /* per-lane closest-hit traversal (pt_trace<closest>, alone or inside a fused launch): BVH node
+                                                       records fetched / triangle records fetched and tested; last render, count_traversal = 1 only */
     uint64_t shadow_nodes_visited, shadow_tris_tested; /* any-hit (shadow) launches, same condition */
     uint64_t wave_rounds, alive_lane_rounds;           /* closest-hit launches: traversal rounds per wave summed, lanes holding a live ray summed */
     float ms_total;            /* last render: HIP-event time around the stage loop */
     float ms_generate, ms_trace_closest, ms_shade, ms_trace_shadow, ms_resolve; /* profile_stages = 1 only */
     uint32_t launches_trace_closest, launches_trace_shadow;
     uint64_t packets;          /* camera-ray waves walked by the packet kernel; last render, count_traversal = 1 only */
+    uint64_t packet_nodes_fetched, packet_tris_fetched; /* packet kernel: records fetched, once per wave of 64 camera rays (count_traversal = 1) */
+    uint64_t fused_shadow_nodes, fused_shadow_tris, fused_shadow_rays; /* the part of the shadow_* counts / of shadow_rays that ran inside fused launches */
+    float ms_trace_packet, ms_trace_fused; /* profile_stages = 1: the packet kernel; the fused shadow(d) + closest(d + 1) launches */
+    uint32_t launches_trace_fused;
     uint32_t bvh_levels, blas_chunks, tlas_nodes; /* 1 / 0 / 0 for a single-level mesh */
     float ms_build_blas, ms_build_tlas, ms_build_flatten; /* two-level meshes: phases of the last build or chunk rebuild (bvh_build_ms = all of it) */
 } rt_pt_stats;

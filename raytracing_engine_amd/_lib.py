@@ -80,7 +80,9 @@ class PtStats(C.Structure):  # rt_pt_stats
                 ("ms_total", C.c_float), ("ms_generate", C.c_float),
                 ("ms_trace_closest", C.c_float), ("ms_shade", C.c_float), ("ms_trace_shadow", C.c_float),
                 ("ms_resolve", C.c_float), ("launches_trace_closest", C.c_uint32), ("launches_trace_shadow", C.c_uint32),
-                ("packets", C.c_uint64), ("bvh_levels", C.c_uint32), ("blas_chunks", C.c_uint32), ("tlas_nodes", C.c_uint32),
+                ("packets", C.c_uint64), ("packet_nodes_fetched", C.c_uint64), ("packet_tris_fetched", C.c_uint64), ("fused_shadow_nodes", C.c_uint64),
+                ("fused_shadow_tris", C.c_uint64), ("fused_shadow_rays", C.c_uint64), ("ms_trace_packet", C.c_float), ("ms_trace_fused", C.c_float),
+                ("launches_trace_fused", C.c_uint32), ("bvh_levels", C.c_uint32), ("blas_chunks", C.c_uint32), ("tlas_nodes", C.c_uint32),
                 ("ms_build_blas", C.c_float), ("ms_build_tlas", C.c_float), ("ms_build_flatten", C.c_float)]
 
     def as_dict(self):

@@ -426,7 +426,8 @@ constexpr int kTrisPerRound = 1;
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st, const uint32_t* __restrict__ queue,
                                             const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
-                                            unsigned long long* __restrict__ stats, TravStack& stk, const uint8_t* perm_lut, uint32_t refill_min) {
+                                            unsigned long long* __restrict__ stats, TravStack& stk, const uint8_t* perm_lut, uint32_t refill_min,
+                                            uint32_t shadow_stat /* word of the shadow-ray node counter: 4 alone, 11 inside the fused launch */ = 4u) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t n = *count_ptr;
@@ -534,8 +535,8 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
                 atomicAdd(&stats[6], (unsigned long long)rounds);
                 atomicAdd(&stats[7], (unsigned long long)alive_rounds);
             }
-            atomicAdd(&stats[ANY ? 4 : 0], a);
-            atomicAdd(&stats[ANY ? 5 : 1], b);
+            atomicAdd(&stats[ANY ? shadow_stat : 0u], a);
+            atomicAdd(&stats[ANY ? shadow_stat + 1u : 1u], b);
         }
     }
     if (tc.overflow) atomicOr((unsigned int*)&stats[2], 1u);
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(256, 8) void pt_trace_fused(const PtScene sc, PtSta
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
     TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
     trace_queue<false, COUNT>(sc, st, queue, closest_count, closest_head, stats, stk, perm_lut, refill_min);
-    trace_queue<true, COUNT>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, perm_lut, refill_min);
+    trace_queue<true, COUNT>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, perm_lut, refill_min, 11u);
 }
 
 // ---- packet trace (camera rays) ---------------------------------------------------------------------
@@ -699,9 +700,9 @@ __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const P
         }
     }
     if (alive) st.hit[pid] = make_float2(best.t, __int_as_float(best.li));
-    if (COUNT && lane == 0) {
-        atomicAdd(&stats[0], (unsigned long long)n_nodes);
-        atomicAdd(&stats[1], (unsigned long long)n_tris);
+    if (COUNT && lane == 0) {  // records fetched once per wave
+        atomicAdd(&stats[9], (unsigned long long)n_nodes);
+        atomicAdd(&stats[10], (unsigned long long)n_tris);
         atomicAdd(&stats[8], 1ull);
     }
     if (overflow && lane == 0) atomicOr((unsigned int*)&stats[2], 1u);

@@ -96,13 +96,15 @@ int ensure_wavefront(Ctx* c, uint64_t n_paths, uint64_t n_slots) {
 }
 
 // Traversal stack + persistent grid.  The first lds_cap entries of every lane's stack live in LDS
-// (8-byte entries: 2 x lds_cap KiB per 256-thread workgroup), which bounds residency at floor(160 KiB / that) workgroups
+// (8-byte entries: 2 x lds_cap KiB per 256-thread workgroup, next to the kernel's 2 KiB octant table), which bounds residency at floor(160 KiB / that) workgroups
 // per CU, 8 at most (32 waves per CU); the rest of the builder's worst case spills to global memory.
 int stack_config(Ctx* c, uint32_t tune_lds, uint32_t tune_blocks, uint64_t n_paths, rt::StackCfg* sk, uint32_t* grid) {
     PtData& pt = c->pt;
     const uint32_t need = std::max<uint32_t>(pt.stack_need, 1u);
-    const uint32_t lds_cap = std::min<uint32_t>(need, tune_lds ? std::min<uint32_t>(tune_lds, 80u) : 8u);
-    const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 80u / lds_cap));  // 2 KiB per entry per workgroup
+    // default: up to ten entries in LDS - the whole stack of the 1 M-triangle tree (depth 9) - at seven workgroups per CU
+    // (measured 1 % ahead of eight entries at eight workgroups)
+    const uint32_t lds_cap = std::min<uint32_t>(need, tune_lds ? std::min<uint32_t>(tune_lds, 78u) : 10u);
+    const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 160u / (2u * lds_cap + 2u)));  // 2 KiB per entry per workgroup + the 2 KiB octant table
     // Few paths (a rank's small share of a frame): fewer resident waves.  Every lane of the grid takes a ray
     // at once, so with ~2 rays per lane the rays in flight span half the frame instead of a compact window
     // and the short launches are all ramp and tail; about four rays per lane and more measured best
@@ -221,13 +223,14 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     RT_HIP(c, hipMemsetAsync(pt.d_stats, 0, kStatWords * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     uint64_t cam = 0, bnc = 0, shd = 0;
-    uint32_t launches_closest = 0, launches_shadow = 0;
+    uint32_t launches_closest = 0, launches_shadow = 0, launches_fused = 0;
+    uint64_t shd_fused = 0;  // shadow rays traced inside fused launches
     // How shadow(d) and closest(d + 1) share the machine (they are independent: the shadow rays only add to the paths'
     // radiance, the closest-hit rays only read rays):  0 (default) one persistent launch pulls from both queues
     // (pt_trace_fused);  2 two launches on two streams (the auxiliary stream exists from the first frame that wants it:
     // streams are dealt onto a few hardware queues in creation order, and a context that only renders path A should
-    // not occupy two);  1, and always under per-stage timing, one launch after the other on one stream.
-    const uint32_t overlap_mode = (tm.on || pt.n_lights == 0) ? 1u : prm->tune_no_overlap;
+    // not occupy two; falls back to 1 under per-stage timing);  1 one launch after the other on one stream.
+    const uint32_t overlap_mode = pt.n_lights == 0 ? 1u : (tm.on && prm->tune_no_overlap == 2u) ? 1u : prm->tune_no_overlap;  // per-stage timing needs one stream
     const bool fused = overlap_mode == 0u;
     if (overlap_mode == 2u && !c->aux_stream) RT_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     const bool overlap = overlap_mode == 2u && c->aux_stream != nullptr;
@@ -272,7 +275,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             uint32_t* ctr_n = pt.d_ctr + (size_t)rt::PT_CTR_STRIDE * (d + 1);
             const uint32_t* q = pt.d_queue[d & 1];
             uint32_t* qn = pt.d_queue[(d + 1) & 1];
-            tm.begin(1);
+            tm.begin(d == 0 && packet ? 5 : shadow_deferred ? 6 : 1);
             if (d == 0 && packet) {  // camera rays: one shared origin, coherent 4x4-pixel blocks per wave
                 if (int rc = rt::launch_pt_trace_packet(c, sc, f, pt.st, pt.d_stats, count)) return rc;
             } else if (shadow_deferred) {  // closest(d) + shadow(d - 1): ctr_d holds both the closest count of depth d and the shadow count of depth d - 1
@@ -281,6 +284,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
                     return rc;
                 shadow_deferred = false;
                 launches_shadow++;
+                launches_fused++;
             } else if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent, stack_cap, refill_min)) {
                 return rc;
             }
@@ -344,6 +348,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             for (uint32_t d = 1; d <= prm->bounces + 1; d++) {
                 if (d <= prm->bounces) bnc += h_ctr[(size_t)rt::PT_CTR_STRIDE * d + rt::PT_CTR_COUNT];
                 shd += h_ctr[(size_t)rt::PT_CTR_STRIDE * d + rt::PT_CTR_SHADOW_COUNT];
+                if (fused && d <= prm->bounces) shd_fused += h_ctr[(size_t)rt::PT_CTR_STRIDE * d + rt::PT_CTR_SHADOW_COUNT];  // shadow(d - 1) rides with closest(d)
             }
         }
     }
@@ -361,14 +366,20 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         pt.stats.shadow_rays = shd;
         pt.stats.nodes_visited = st[0];
         pt.stats.tris_tested = st[1];
-        pt.stats.shadow_nodes_visited = st[4];
-        pt.stats.shadow_tris_tested = st[5];
+        pt.stats.shadow_nodes_visited = st[4] + st[11];
+        pt.stats.shadow_tris_tested = st[5] + st[12];
+        pt.stats.fused_shadow_nodes = st[11];
+        pt.stats.fused_shadow_tris = st[12];
+        pt.stats.packet_nodes_fetched = st[9];
+        pt.stats.packet_tris_fetched = st[10];
+        pt.stats.fused_shadow_rays = shd_fused;
+        pt.stats.launches_trace_fused = launches_fused;
         pt.stats.wave_rounds = st[6];
         pt.stats.alive_lane_rounds = st[7];
         pt.stats.packets = st[8];
         pt.stats.stack_overflow = (uint32_t)st[2];
         RT_HIP(c, hipEventElapsedTime(&pt.stats.ms_total, c->ev_begin, c->ev_end));
-        float sums[5] = {};
+        float sums[7] = {};
         if (tm.on) {
             for (auto& m : tm.marks) {
                 float ms = 0.0f;
@@ -380,6 +391,8 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         pt.stats.ms_shade = sums[2];
         pt.stats.ms_trace_shadow = sums[3];
         pt.stats.ms_resolve = sums[4];
+        pt.stats.ms_trace_packet = sums[5];
+        pt.stats.ms_trace_fused = sums[6];
     }
     return RT_OK;
 }

@@ -74,13 +74,13 @@ def path_a(name, w, h, spp, gpu=True):
         rays = st["primary_rays"] + st["shadow_rays"]
         row["gpu_ms"], row["gpu_mrays"] = ms, rays / ms / 1e3
         row["max_abs_err"] = float(np.abs(r.render(spp=spp) - ref).max())
-        row["roofline_frac"] = (w * h * spp * 27.0) / (ms * 1e-3) / 8e12
+        row["algorithmic_over_hbm_peak"] = (w * h * spp * 27.0) / (ms * 1e-3) / 8e12
     rows.append(row)
 
 
-def path_b(name, n_tris, edge, w, h, spp, bounces, cpu_rows, cpu_spp):
+def path_b(name, n_tris, edge, w, h, spp, bounces, cpu_rows, cpu_spp, levels=1, cpu=True):
     mesh = R.scenes.soup_scene(n_tris, seed=1, edge=edge)
-    r.set_mesh(*mesh)
+    r.set_mesh(*mesh, bvh_levels=levels)
     r.resize(w, h)
     sky = (0.2, 0.2, 0.25)
     prm = r.pt_params(spp=spp, bounces=bounces, seed=1, sky=sky)
@@ -95,16 +95,23 @@ def path_b(name, n_tris, edge, w, h, spp, bounces, cpu_rows, cpu_spp):
     r.render_pt(params=r.pt_params(spp=min(spp, 4), bounces=bounces, seed=1, sky=sky, count_traversal=True))
     ct = r.pt_stats()
     nr = ct["camera_rays"] + ct["bounce_rays"] + ct["shadow_rays"]
-    bytes_per_ray = ((ct["nodes_visited"] + ct["shadow_nodes_visited"]) * 80.0 + (ct["tris_tested"] + ct["shadow_tris_tested"]) * 48.0) / nr + 45.0
+    # records fetched: once per ray by the per-lane kernels, once per wave of 64 camera rays by the packet kernel
+    bytes_per_ray = ((ct["nodes_visited"] + ct["shadow_nodes_visited"] + ct["packet_nodes_fetched"]) * 80.0
+                     + (ct["tris_tested"] + ct["shadow_tris_tested"] + ct["packet_tris_fetched"]) * 48.0) / nr + 45.0
     row = {"config": name, "oracle": "B", "gpu_ms": ms, "gpu_mrays": rays / ms / 1e3, "rays": rays,
-           "alg_bytes": f"{bytes_per_ray:.0f} B/ray", "roofline_frac": rays * bytes_per_ray / (ms * 1e-3) / 8e12,
-           "bvh_nodes": st["n_nodes"], "bvh_build_ms": st["bvh_build_ms"]}
+           "alg_bytes": f"{bytes_per_ray:.0f} B/ray", "algorithmic_over_hbm_peak": rays * bytes_per_ray / (ms * 1e-3) / 8e12,
+           "bvh_nodes": st["n_nodes"], "bvh_levels": st["bvh_levels"], "bvh_build_ms": st["bvh_build_ms"]}
     # parity on a band of the full-size frame
     gpu = r.render_pt(params=prm)
     osc = O.TriScene(*mesh)
     y0 = h // 2
     band, _ = osc.render(w, h, spp=spp, bounces=bounces, seed=1, sky=sky, rows=(y0, y0 + 4), threads=threads)
     row["max_abs_err"] = float(np.abs(gpu[y0:y0 + 4] - band).max())
+
+    if not cpu:
+        row["cpu_cores"] = threads
+        rows.append(row)
+        return
 
     def cpu(th):
         t0 = time.perf_counter()
@@ -123,15 +130,16 @@ def path_b(name, n_tris, edge, w, h, spp, bounces, cpu_rows, cpu_spp):
 
 path_a("1: 8 spheres + 1 light, 256x256, 1 spp (CPU only)", 256, 256, 1, gpu=False)
 path_a("2: same scene, 1920x1080, 4 spp", 1920, 1080, 4)
-path_b("3: 100 k triangles, 1920x1080, 4 spp, 1 bounce", 100_000, 0.25, 1920, 1080, 4, 1, (0, 1080), 1)
+path_b("3: 100 k triangles, single-level BVH8, 1920x1080, 4 spp, 1 bounce", 100_000, 0.25, 1920, 1080, 4, 1, (0, 1080), 1)
+path_b("3 (two-level BVH: top level over 64 chunks): as 3", 100_000, 0.25, 1920, 1080, 4, 1, (0, 1080), 1, levels=2, cpu=False)
 path_b("4: 1 M triangles, 1920x1080, 8 spp, 1 bounce (1 GPU of 8)", 1_000_000, 0.08, 1920, 1080, 8, 1, (0, 1080), 1)
 path_b("5: 1 M triangles, 3840x2160, 64 spp, 8 bounces (1 GPU of 8)", 1_000_000, 0.08, 3840, 2160, 64, 8, (1000, 1128), 1)
 
-print("| # | config | oracle | CPU Mrays/s (1 core) | CPU Mrays/s (N cores) | N | 1 GPU Mrays/s | ms/frame | alg. bytes | roofline frac | max-abs RGB err |")
+print("| # | config | oracle | CPU Mrays/s (1 core) | CPU Mrays/s (N cores) | N | 1 GPU Mrays/s | ms/frame | alg. bytes | alg. bytes/s over HBM peak | max-abs RGB err |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 for x in rows:
     f = lambda k, fmt="{:.1f}": fmt.format(x[k]) if x.get(k) is not None else "n/a"
     print(f"| {x['config'][:1]} | {x['config'][3:]} | {x['oracle']} | {f('cpu_1core_mrays', '{:.2f}')} | {f('cpu_ncore_mrays', '{:.2f}')} | {x['cpu_cores']} | "
-          f"{f('gpu_mrays')} | {f('gpu_ms', '{:.3f}')} | {x['alg_bytes']} | {f('roofline_frac', '{:.3f}')} | {f('max_abs_err', '{:.2e}')} |")
+          f"{f('gpu_mrays')} | {f('gpu_ms', '{:.3f}')} | {x['alg_bytes']} | {f('algorithmic_over_hbm_peak', '{:.3f}')} | {f('max_abs_err', '{:.2e}')} |")
 if a.out:
     json.dump(rows, open(a.out, "w"), indent=1)
