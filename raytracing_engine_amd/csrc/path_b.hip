@@ -745,9 +745,10 @@ __global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, con
                 L.z = __builtin_fmaf(T.z, f.sky[2], L.z);
                 st.rad[pid] = L;
             } else {
-                const float4 em = sc.emission[li];
-                if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {  // lights are seen directly only by camera rays
+                const float4 ta = sc.tris[(size_t)li * 3 + 0], tb = sc.tris[(size_t)li * 3 + 1], tc = sc.tris[(size_t)li * 3 + 2];
+                if (__float_as_uint(tc.z) != 0u) {  // emissive (flag in the triangle record); lights are seen directly only by camera rays
                     if (depth == 0) {
+                        const float4 em = sc.emission[li];
                         L.x = __builtin_fmaf(T.x, em.x, L.x);
                         L.y = __builtin_fmaf(T.y, em.y, L.y);
                         L.z = __builtin_fmaf(T.z, em.z, L.z);
@@ -755,7 +756,6 @@ __global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, con
                     }
                 } else {
                     const float4 alb = sc.albedo[li];
-                    const float4 ta = sc.tris[(size_t)li * 3 + 0], tb = sc.tris[(size_t)li * 3 + 1], tc = sc.tris[(size_t)li * 3 + 2];
                     v3 nrm = normalize(cross(mk(ta.w, tb.x, tb.y), mk(tb.z, tb.w, tc.x)));
                     if (dot(nrm, d) > 0.0f) nrm = -nrm;
                     const v3 pt = fma3(d, hrec.x, o);

@@ -476,7 +476,11 @@ void pack_leaf_range(const rt::BvhResult& bvh, const float* v0, const float* e1,
         r[4] = e1[3 * (size_t)t + 1]; r[5] = e1[3 * (size_t)t + 2]; r[6] = e2[3 * (size_t)t]; r[7] = e2[3 * (size_t)t + 1];
         r[8] = e2[3 * (size_t)t + 2];
         std::memcpy(&r[9], &t, 4);
-        r[10] = r[11] = 0.0f;
+        // word 10: 1 = emissive.  pt_shade reads the record anyway (normal) and skips the 16-byte emission gather for the
+        // triangles that are not lights - all but a handful
+        const uint32_t is_light = (emission[3 * (size_t)t] > 0.0f || emission[3 * (size_t)t + 1] > 0.0f || emission[3 * (size_t)t + 2] > 0.0f) ? 1u : 0u;
+        std::memcpy(&r[10], &is_light, 4);
+        r[11] = 0.0f;
         for (int a = 0; a < 3; a++) {
             alb[4 * (li - li0) + a] = albedo[3 * (size_t)t + a];
             emi[4 * (li - li0) + a] = emission[3 * (size_t)t + a];

@@ -128,7 +128,7 @@ enum {
 
 struct PtScene {
     const float4* nodes;     // 5 x float4 (80 B) per compressed 8-wide BVH node (bvh_build.h layout)
-    const float4* tris;      // 3 x float4 per triangle, leaf order: v0.xyz e1.x | e1.yz e2.xy | e2.z id - -
+    const float4* tris;      // 3 x float4 per triangle, leaf order: v0.xyz e1.x | e1.yz e2.xy | e2.z id emissive-flag -
     const float4* albedo;    // leaf order
     const float4* emission;  // leaf order
     const uint32_t* lights;  // leaf-order indices of emissive triangles, ascending original id
