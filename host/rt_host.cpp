@@ -8,7 +8,7 @@
 //
 //   rt_host [--size WxH] [--yaw R] [--pitch R] [--pos x,y,z] [--move right,forward,up] [--spp N]
 //           [--scene default|soup:N] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm]
-//           [--march 1|2|3] [--repeat x,y,z] [--inflight K]
+//           [--march 1|2|3] [--repeat x,y,z] [--mirror N[,reflectivity]] [--inflight K]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -105,8 +105,8 @@ int main(int argc, char** argv) {
     uint32_t w = 1024, h = 768, spp = 1, bounces = 1, seed = 1, frames = 1;
     float yaw = 0.0f, pitch = 0.0f, pos[3] = {0, 0, 0}, move[3] = {0, 0, 0};
     std::string scene = "default", out = "frame.ppm";
-    uint32_t march = 0, inflight = 0;
-    float repeat[3] = {0, 0, 0};
+    uint32_t march = 0, inflight = 0, mirror = 0;
+    float repeat[3] = {0, 0, 0}, reflectivity = 0.5f;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -123,11 +123,12 @@ int main(int argc, char** argv) {
         else if (a == "--out") out = next();
         else if (a == "--march") march = (uint32_t)std::atoi(next());
         else if (a == "--repeat") std::sscanf(next(), "%f,%f,%f", &repeat[0], &repeat[1], &repeat[2]);
+        else if (a == "--mirror") std::sscanf(next(), "%u,%f", &mirror, &reflectivity);
         else if (a == "--inflight") inflight = (uint32_t)std::atoi(next());
         else {
             std::fprintf(stderr, "usage: rt_host [--size WxH] [--yaw R] [--pitch R] [--pos x,y,z] [--move r,f,u] [--spp N] "
                                  "[--scene default|soup:N] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm] "
-                                 "[--march 1|2|3] [--repeat x,y,z] [--inflight K]\n");
+                                 "[--march 1|2|3] [--repeat x,y,z] [--mirror N[,reflectivity]] [--inflight K]\n");
             return 2;
         }
     }
@@ -169,11 +170,13 @@ int main(int argc, char** argv) {
         rt_mutable_data s;
         rt_default_scene(&s);  // src/main.rs:524-591
         if ((rc = rt_set_scene(ctx, &s, sizeof s))) return fail(ctx, "rt_set_scene", rc);
-        if (march || repeat[0] > 0 || repeat[1] > 0 || repeat[2] > 0) {  // the march loops / repeat() the author sketched
+        if (march || mirror || repeat[0] > 0 || repeat[1] > 0 || repeat[2] > 0) {  // the march loops / repeat() / reflections the author sketched
             rt_config cfg;
             rt_default_config(&cfg);
             cfg.march_algorithm = march;
             for (int a = 0; a < 3; a++) cfg.repeat[a] = repeat[a];
+            cfg.reflections = mirror;
+            cfg.reflectivity = reflectivity;
             if ((rc = rt_set_config(ctx, &cfg))) return fail(ctx, "rt_set_config", rc);
         }
     }

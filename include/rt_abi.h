@@ -90,13 +90,20 @@ typedef struct rt_config {
                                  1, 2 = shaders/tracing_algorithms.txt:2-13 / :16-37 in the same loop */
     float repeat[3];          /* > 0: domain repetition period on that axis, repeat() of utilities.glsl:31-34,
                                  applied to the position of every SDF evaluation and of the surface normal */
+    uint32_t reflections;     /* mirror bounces, 0..8 (shaders/fragment.glsl:125 "TODO: reflection"; build-defined): after
+                                 shading a hit P seen along `step`, r = reflect(step, normal) starts one unit off the surface
+                                 (the shadowRay idiom, fragment.glsl:176) and is marched by compute.glsl's loop (:44-66) with
+                                 cone threshold RAY_RADIUS: len = 1 + traceCone(P + r, r, RAY_RADIUS); a hit at
+                                 P + r * max(len, 0) is shaded by fragment.glsl:144-186 with P as the eye and added with
+                                 weight prod(reflectivity * mat.specular) over the surfaces passed */
+    float reflectivity;       /* 0..1, default 0.5 (mat.specular, which the reference never reads, scales it per material) */
 } rt_config;
 
 typedef struct rt_stats {
     uint32_t width, height, level_count, spp;
     uint64_t frames;           /* rt_render* calls since rt_resize */
     uint64_t primary_rays;     /* last call: width*height*spp (owned tiles only) */
-    uint64_t shadow_rays;      /* last call: lightCount per hit pixel per sample */
+    uint64_t shadow_rays;      /* last call: lightCount per shaded surface point (hit pixel samples + reflection hits) */
     uint64_t hit_pixels;       /* last call */
     uint64_t cone_threads;     /* last call: compute-stage invocations over all levels */
     float    ms_total;         /* last call: HIP-event time around the whole stage loop */
@@ -104,6 +111,7 @@ typedef struct rt_stats {
     float    ms_shade;         /* last call: shade kernel(s) (profile_stages=1 only) */
     float    ms_level[RT_MAX_LEVELS]; /* last call, last sample (profile_stages=1, fuse_levels=0 only) */
     float    ms_fused;         /* last call, last sample: the one-launch pyramid kernel (profile_stages=1, fuse_levels=1) */
+    uint64_t reflection_rays;  /* last call: mirror rays marched (rt_config.reflections > 0) */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

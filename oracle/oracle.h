@@ -60,6 +60,14 @@ typedef struct {
     uint32_t march_algorithm; /* cone march loop body: 0 or 3 = compute.glsl:46-65 ("algorithm 3"),
                                  1, 2 = shaders/tracing_algorithms.txt:2-13 / :16-37 */
     float repeat[3];          /* > 0: domain repetition period on that axis, utilities.glsl:31-34 */
+    /* mirror reflections (fragment.glsl:125 "TODO: reflection"; build-defined): 0 = off = the reference
+     * as shipped.  After shading a hit point P seen along the unit direction `step`: r = reflect(step, normal); the ray
+     * starts one unit off the surface (the reference's shadowRay idiom, fragment.glsl:176) and is marched by compute.glsl's
+     * own loop (:44-66) with cone threshold RAY_RADIUS: len = 1 + traceCone(P + r, r, RAY_RADIUS); a hit (len < RENDER_DIST)
+     * at P' = P + r * max(len, 0) is shaded by fragment.glsl:144-186 with P as the eye, and added with weight
+     * prod(reflectivity * mat.specular) over the surfaces passed; at most `reflections` bounces. */
+    uint32_t reflections;
+    float reflectivity;
 } ora_config;
 
 typedef struct {
@@ -70,6 +78,7 @@ typedef struct {
     uint64_t shadow_rays;   /* shadowRay calls (= hit_pixels * lightCount) */
     uint64_t shadow_steps;  /* iterations of fragment.glsl:99-119 */
     uint64_t shadow_sdf;    /* sphereSDF evaluations inside shadowRay */
+    uint64_t reflection_rays; /* mirror rays marched (reflections > 0) */
 } ora_counters;
 
 void ora_default_config(ora_config* cfg);

@@ -69,6 +69,8 @@ void ora_default_config(ora_config* cfg) {
     cfg->max_steps = 1u << 20;
     cfg->march_algorithm = 0;
     cfg->repeat[0] = cfg->repeat[1] = cfg->repeat[2] = 0.0f;
+    cfg->reflections = 0;    /* the reference has none (fragment.glsl:125 is a TODO) */
+    cfg->reflectivity = 0.5f;
 }
 
 /* src/main.rs:524-591 */
@@ -287,23 +289,10 @@ static inline float cone_pixel(const ora_scene* sc, const ora_config* cfg, uint3
     return fmaxf(len, 0.0f); /* :86 */
 }
 
-/* ---- shaders/fragment.glsl:127-187 main, one invocation -------------------------------- */
-static inline void shade_pixel(const ora_scene* sc, const ora_config* cfg, uint32_t px, uint32_t py, const float view[2],
-                               const float ratio[2], const float rot[4], v3 pos, const float jitter[2], float total_dist,
-                               float out[3], ora_counters* ct) {
-    /* :129  gl_FragCoord.xy * 2 / cs.view - 1.0, gl_FragCoord = pixel + 0.5 */
-    float nx = (((float)px + 0.5f) * 2.0f) / view[0] - 1.0f + jitter[0];
-    float ny = (((float)py + 0.5f) * 2.0f) / view[1] - 1.0f + jitter[1];
-    nx *= ratio[0]; /* :131 */
-    ny *= ratio[1];
-    v3 step = v3_normalize(rotate_q(rot, v3_make(nx, 1.0f, ny))); /* :133 */
-
-    out[0] = out[1] = out[2] = 0.0f;
-    if (total_dist >= cfg->render_dist) return; /* :137-140 */
-    ct->hit_pixels++;
-
-    v3 position = v3_fma(step, total_dist, pos); /* :142 */
-
+/* ---- shaders/fragment.glsl:144-186: nearest sphere, material, light loop for surface point `position` seen from `eye`
+ * along the unit direction `step` (for the camera ray eye = push_constants.pos; for a mirror bounce the previous hit) ---- */
+static inline void shade_point(const ora_scene* sc, const ora_config* cfg, v3 position, v3 eye, v3 step, float out[3], v3* normal_out,
+                               float* specular_out, ora_counters* ct) {
     /* :144-156 nearest sphere, strict '<', material index = object index */
     uint32_t best = 0;
     float dist = sphere_sdf(position, &sc->objs[0], cfg);
@@ -314,7 +303,7 @@ static inline void shade_pixel(const ora_scene* sc, const ora_config* cfg, uint3
     const ora_object* object = &sc->objs[best];
     const ora_material* mat = &sc->mats[best];
 
-    float cam_dist = v3_length(v3_sub(position, pos));                              /* :162 */
+    float cam_dist = v3_length(v3_sub(position, eye));                              /* :162 */
     float cam_fall = fmaxf(cfg->cam_fall_off * fmaf(cam_dist, cam_dist, 1.0f), 1.0f); /* :163 */
     v3 normal = v3_normalize(v3_sub(domain(position, cfg), v3_load(object->pos)));  /* :166, :39-41 */
     v3 cam_dir = v3_neg(step);
@@ -339,7 +328,7 @@ static inline void shade_pixel(const ora_scene* sc, const ora_config* cfg, uint3
         v3 refl = v3_make(fmaf(-k, normal.x, inc.x), fmaf(-k, normal.y, inc.y), fmaf(-k, normal.z, inc.z));
         float base = v3_dot(refl, cam_dir);
         /* pow(negative, y) is undefined in GLSL (NaN on GPUs, then max(NaN,0) = 0): defined
-         * here as 0 for base <= 0 (DESIGN.md §4) */
+         * here as 0 for base <= 0 (DESIGN.md section 4) */
         float spec = base > 0.0f ? fmaxf(diffuse * powf(base, mat->shine), 0.0f) : 0.0f;
 
         float s = fmaxf(diffuse + spec, 0.0f); /* :183 */
@@ -352,6 +341,49 @@ static inline void shade_pixel(const ora_scene* sc, const ora_config* cfg, uint3
         b = fmaf(((mat->ambient + db) / cam_fall) * normal_fall, mat->color[2], b);
     }
     out[0] = r; out[1] = g; out[2] = b;
+    *normal_out = normal;
+    *specular_out = mat->specular;
+}
+
+/* ---- shaders/fragment.glsl:127-187 main, one invocation -------------------------------- */
+static inline void shade_pixel(const ora_scene* sc, const ora_config* cfg, uint32_t px, uint32_t py, const float view[2],
+                               const float ratio[2], const float rot[4], v3 pos, const float jitter[2], float total_dist,
+                               float out[3], ora_counters* ct) {
+    /* :129  gl_FragCoord.xy * 2 / cs.view - 1.0, gl_FragCoord = pixel + 0.5 */
+    float nx = (((float)px + 0.5f) * 2.0f) / view[0] - 1.0f + jitter[0];
+    float ny = (((float)py + 0.5f) * 2.0f) / view[1] - 1.0f + jitter[1];
+    nx *= ratio[0]; /* :131 */
+    ny *= ratio[1];
+    v3 step = v3_normalize(rotate_q(rot, v3_make(nx, 1.0f, ny))); /* :133 */
+
+    out[0] = out[1] = out[2] = 0.0f;
+    if (total_dist >= cfg->render_dist) return; /* :137-140 */
+    ct->hit_pixels++;
+
+    v3 position = v3_fma(step, total_dist, pos); /* :142 */
+    v3 normal;
+    float specular;
+    shade_point(sc, cfg, position, pos, step, out, &normal, &specular, ct);
+
+    /* mirror reflections - build-defined (fragment.glsl:125 is a TODO), specified at ora_config.reflections in oracle.h */
+    float weight = 1.0f;
+    for (uint32_t bounce = 0; bounce < cfg->reflections; bounce++) {
+        weight *= cfg->reflectivity * specular;
+        const float k = 2.0f * v3_dot(normal, step);
+        const v3 r = v3_make(fmaf(-k, normal.x, step.x), fmaf(-k, normal.y, step.y), fmaf(-k, normal.z, step.z)); /* reflect(step, normal) */
+        uint64_t dummy_steps = 0, dummy_sdf = 0;
+        ct->reflection_rays++;
+        const float len = 1.0f + trace_cone3(sc, cfg, v3_add(position, r), r, cfg->ray_radius, &dummy_steps, &dummy_sdf);
+        if (!(len < cfg->render_dist)) break;
+        const v3 hit = v3_fma(r, fmaxf(len, 0.0f), position);
+        float rgb[3];
+        shade_point(sc, cfg, hit, position, r, rgb, &normal, &specular, ct);
+        out[0] = fmaf(weight, rgb[0], out[0]);
+        out[1] = fmaf(weight, rgb[1], out[1]);
+        out[2] = fmaf(weight, rgb[2], out[2]);
+        position = hit;
+        step = r;
+    }
 }
 
 static int scene_valid(const ora_scene* s) {
@@ -404,17 +436,17 @@ int ora_render_a(const ora_scene* scene, const ora_config* cfg, uint32_t width, 
     }
     /* src/main.rs:318-338: full-screen draw, fragment shader reads the last level */
     if (rgb) {
-        uint64_t hit = 0, srays = 0, ssteps = 0, ssdf = 0;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : hit, srays, ssteps, ssdf)
+        uint64_t hit = 0, srays = 0, ssteps = 0, ssdf = 0, rrays = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : hit, srays, ssteps, ssdf, rrays)
         for (uint32_t py = 0; py < height; py++) {
             ora_counters ct;
             memset(&ct, 0, sizeof ct);
             for (uint32_t px = 0; px < width; px++)
                 shade_pixel(scene, cfg, px, py, view, ratio, rot, p, jitter, prev[(size_t)py * prev_w + px],
                             rgb + ((size_t)py * width + px) * 3, &ct);
-            hit += ct.hit_pixels; srays += ct.shadow_rays; ssteps += ct.shadow_steps; ssdf += ct.shadow_sdf;
+            hit += ct.hit_pixels; srays += ct.shadow_rays; ssteps += ct.shadow_steps; ssdf += ct.shadow_sdf; rrays += ct.reflection_rays;
         }
-        total.hit_pixels = hit; total.shadow_rays = srays; total.shadow_steps = ssteps; total.shadow_sdf = ssdf;
+        total.hit_pixels = hit; total.shadow_rays = srays; total.shadow_steps = ssteps; total.shadow_sdf = ssdf; total.reflection_rays = rrays;
     }
     free(prev);
     if (counters) *counters = total;

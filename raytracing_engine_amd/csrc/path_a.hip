@@ -211,29 +211,19 @@ __device__ __forceinline__ float4 pick8(const float4 (&a)[8], uint32_t i) {
     return v;
 }
 
-// ---- shaders/fragment.glsl:127-187 ------------------------------------------------------------
-// One invocation of fragment.glsl:main for full-resolution pixel (px, py) whose depth is total_dist.
-// Returns true for a hit pixel; rgb = 0 for a miss (:137-140).
+// ---- shaders/fragment.glsl:144-186 ------------------------------------------------------------
+// Nearest sphere, material and light loop for surface point `position` seen from `eye` along the unit direction `step`
+// (camera ray: eye = push_constants.pos; mirror bounce: the previous hit).  Returns the normal and the material's
+// specular coefficient for a following mirror bounce.
 template <int N, bool REP>
-__device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams p, float jx, float jy, uint32_t px, uint32_t py, float total_dist, float& r,
-                                            float& g, float& b) {
-    r = g = b = 0.0f;
-    if (!(total_dist < p.render_dist)) return false;  // :137-140
-    // :129-133  gl_FragCoord.xy * 2 / cs.view - 1.0   (gl_FragCoord = pixel + 0.5)
-    float nx = (((float)px + 0.5f) * 2.0f) / p.view[0] - 1.0f + jx;
-    float ny = (((float)py + 0.5f) * 2.0f) / p.view[1] - 1.0f + jy;
-    nx *= p.cam.ratio[0];
-    ny *= p.cam.ratio[1];
-    const v3 step = normalize(rotate_q(p.cam.rot[0], p.cam.rot[1], p.cam.rot[2], p.cam.rot[3], mk(nx, 1.0f, ny)));
-    const v3 pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
-    const v3 position = fma3(step, total_dist, pos);  // :142
-
+__device__ __forceinline__ void shade_point(const ShadeSet& S, const ShadeParams& p, v3 position, v3 eye, v3 step, float& r, float& g, float& b, v3& normal_out,
+                                            float& specular_out) {
     // :144-156 nearest sphere (strict '<', first wins ties); material index = object index
     const Rep rep{p.repeat[0], p.repeat[1], p.repeat[2]};
     float dist = sphere_sdf<REP>(position, S.sphere[0], rep);
     float4 obj = S.sphere[0];
     float4 mat = S.mat_color_ambient[0];
-    float shine = S.mat_shine[0];
+    float shine = S.mat_shine[0], specular = S.mat_specular[0];
 #pragma unroll
     for (int i = 1; i < N; i++) {
         const float nd = sphere_sdf<REP>(position, S.sphere[i], rep);
@@ -242,15 +232,17 @@ __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams 
             obj = S.sphere[i];
             mat = S.mat_color_ambient[i];
             shine = S.mat_shine[i];
+            specular = S.mat_specular[i];
         }
     }
 
-    const float cam_dist = length(position - pos);                                                    // :162
+    const float cam_dist = length(position - eye);                                                   // :162
     const float cam_fall = fmax_(p.cam_fall_off * __builtin_fmaf(cam_dist, cam_dist, 1.0f), 1.0f);   // :163
     const v3 normal = normalize(domain<REP>(position, rep) - mk(obj.x, obj.y, obj.z));                // :166
     const v3 cam_dir = -step;
     const float normal_fall = fmax_(dot(normal, cam_dir), 0.0f);  // :167
 
+    r = g = b = 0.0f;
     for (uint32_t i = 0; i < S.light_count; i++) {  // :170-186
         const float4 lp = pick8(S.light_pos, i), lc = pick8(S.light_color, i);
         const v3 lpos = mk(lp.x, lp.y, lp.z);
@@ -264,7 +256,7 @@ __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams 
         const float kk = 2.0f * dot(normal, inc);
         const v3 refl = mk(__builtin_fmaf(-kk, normal.x, inc.x), __builtin_fmaf(-kk, normal.y, inc.y), __builtin_fmaf(-kk, normal.z, inc.z));
         const float base = dot(refl, cam_dir);
-        // pow(x<=0, y) is undefined in GLSL; defined as 0 here (DESIGN.md §4)
+        // pow(x<=0, y) is undefined in GLSL; defined as 0 here (DESIGN.md section 4)
         const float spec = base > 0.0f ? fmax_(diffuse * __builtin_powf(base, shine), 0.0f) : 0.0f;
         const float s = fmax_(diffuse + spec, 0.0f);  // :183
         const float dr = ((s * lc.x) / light_fall) * soft;
@@ -275,11 +267,59 @@ __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams 
         g = __builtin_fmaf(((mat.w + dg) / cam_fall) * normal_fall, mat.y, g);
         b = __builtin_fmaf(((mat.w + db) / cam_fall) * normal_fall, mat.z, b);
     }
+    normal_out = normal;
+    specular_out = specular;
+}
+
+// ---- shaders/fragment.glsl:127-187 ------------------------------------------------------------
+// One invocation of fragment.glsl:main for full-resolution pixel (px, py) whose depth is total_dist.
+// Returns true for a hit pixel; rgb = 0 for a miss (:137-140).  REFL: mirror reflections (fragment.glsl:125 is a TODO in the
+// reference; build-defined, specification at rt_config.reflections / oracle.h): r = reflect(step, normal), the ray starts one
+// unit off the surface (the shadowRay idiom of :176) and is marched by compute.glsl's own loop with cone threshold RAY_RADIUS;
+// a hit is shaded with the previous hit as the eye and added with weight prod(reflectivity * mat.specular).
+// n_points / n_refl count the shaded reflection hits and the mirror rays of this lane.
+template <int N, bool REP, bool REFL>
+__device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams p, float jx, float jy, uint32_t px, uint32_t py, float total_dist, float& r,
+                                            float& g, float& b, uint32_t& n_points, uint32_t& n_refl) {
+    r = g = b = 0.0f;
+    if (!(total_dist < p.render_dist)) return false;  // :137-140
+    // :129-133  gl_FragCoord.xy * 2 / cs.view - 1.0   (gl_FragCoord = pixel + 0.5)
+    float nx = (((float)px + 0.5f) * 2.0f) / p.view[0] - 1.0f + jx;
+    float ny = (((float)py + 0.5f) * 2.0f) / p.view[1] - 1.0f + jy;
+    nx *= p.cam.ratio[0];
+    ny *= p.cam.ratio[1];
+    v3 step = normalize(rotate_q(p.cam.rot[0], p.cam.rot[1], p.cam.rot[2], p.cam.rot[3], mk(nx, 1.0f, ny)));
+    const v3 pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+    v3 position = fma3(step, total_dist, pos);  // :142
+    v3 normal;
+    float specular;
+    shade_point<N, REP>(S, p, position, pos, step, r, g, b, normal, specular);
+    if (REFL) {
+        const Rep rep{p.repeat[0], p.repeat[1], p.repeat[2]};
+        float weight = 1.0f;
+        for (uint32_t bounce = 0; bounce < p.reflections; bounce++) {
+            weight *= p.reflectivity * specular;
+            const float kk = 2.0f * dot(normal, step);
+            const v3 rd = mk(__builtin_fmaf(-kk, normal.x, step.x), __builtin_fmaf(-kk, normal.y, step.y), __builtin_fmaf(-kk, normal.z, step.z));
+            n_refl++;
+            const float len = 1.0f + trace_cone<N, 3, REP>(S.sphere, position + rd, rd, p.ray_radius, p.render_dist, p.max_steps, rep);
+            if (!(len < p.render_dist)) break;
+            const v3 hit = fma3(rd, fmax_(len, 0.0f), position);
+            float rr, rg, rb;
+            shade_point<N, REP>(S, p, hit, position, rd, rr, rg, rb, normal, specular);
+            n_points++;
+            r = __builtin_fmaf(weight, rr, r);
+            g = __builtin_fmaf(weight, rg, g);
+            b = __builtin_fmaf(weight, rb, b);
+            position = hit;
+            step = rd;
+        }
+    }
     return true;
 }
 
 // Grid: 16 workgroups per owned framebuffer tile; every wave shades one 8x8 block of the tile.
-template <int N, bool REP>
+template <int N, bool REP, bool REFL>
 __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const ShadeParams p, const float* __restrict__ depth,
                                                     float* __restrict__ dst, uint64_t* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -302,11 +342,11 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
         b = dst[idx * 3 + 2];
         have_sum = true;
     }
-    uint32_t n_hits = 0;
+    uint32_t n_hits = 0, n_points = 0, n_refl = 0;
     for (uint32_t sb = 0; sb < p.n_batch; sb++) {
         float jx, jy, sr, sg, sbl;
         sample_jitter(p.sample0 + sb, p.n_strata, p.width, p.height, &jx, &jy);
-        const bool hit = inside && shade_pixel<N, REP>(S, p, jx, jy, px, py, depth[(size_t)sb * p.depth_stride + (size_t)py * p.depth_w + px], sr, sg, sbl);  // :135
+        const bool hit = inside && shade_pixel<N, REP, REFL>(S, p, jx, jy, px, py, depth[(size_t)sb * p.depth_stride + (size_t)py * p.depth_w + px], sr, sg, sbl, n_points, n_refl);  // :135
         if (have_sum) {
             r += sr;
             g += sg;
@@ -322,6 +362,17 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
     // hit-pixel statistics: one atomic per wave, spread over 1024 slots (a single hot word serves only
     // ~90 atomics/us chip-wide and made this kernel atomic-bound); the host sums the slots
     if (lane == 0 && n_hits) atomicAdd((unsigned long long*)&counters[blockIdx.x & 1023u], (unsigned long long)n_hits);
+    if (REFL) {  // reflection hits shaded / mirror rays marched: slots 1024.. and 2048..
+        unsigned long long pts = n_points, rays = n_refl;
+        for (int off = 32; off > 0; off >>= 1) {
+            pts += __shfl_down(pts, off);
+            rays += __shfl_down(rays, off);
+        }
+        if (lane == 0 && rays) {
+            atomicAdd((unsigned long long*)&counters[1024u + (blockIdx.x & 1023u)], pts);
+            atomicAdd((unsigned long long*)&counters[2048u + (blockIdx.x & 1023u)], rays);
+        }
+    }
 
     if (inside) {
         if (p.mode & 2u) {
@@ -472,8 +523,15 @@ static void cone_launch_n(hipStream_t st, dim3 grid, const SphereSet& S, const C
 template <int N>
 static void shade_launch_n(hipStream_t st, dim3 grid, const ShadeSet& S, const ShadeParams& p, const float* depth, float* dst,
                            uint64_t* counters) {
-    if (p.repeat[0] > 0.0f || p.repeat[1] > 0.0f || p.repeat[2] > 0.0f) hipLaunchKernelGGL((shade_kernel<N, true>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
-    else hipLaunchKernelGGL((shade_kernel<N, false>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
+    const bool rep = p.repeat[0] > 0.0f || p.repeat[1] > 0.0f || p.repeat[2] > 0.0f;
+    // the reference as shipped (no reflections, no repetition) first; the sketched variants behind it
+    if (p.reflections == 0) {
+        if (rep) hipLaunchKernelGGL((shade_kernel<N, true, false>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
+        else hipLaunchKernelGGL((shade_kernel<N, false, false>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
+    } else {
+        if (rep) hipLaunchKernelGGL((shade_kernel<N, true, true>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
+        else hipLaunchKernelGGL((shade_kernel<N, false, true>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
+    }
 }
 
 int launch_cone_level(Ctx* c, const SphereSet& S, uint32_t n_obj, const ConeLevelParams& p, const float* parent, float* out, uint32_t batch) {

@@ -18,17 +18,19 @@ from raytracing_engine_amd import host  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def case(name, scene_bytes, w, h, rot, pos, march_algorithm=0, repeat=(0.0, 0.0, 0.0), max_steps=None):
+def case(name, scene_bytes, w, h, rot, pos, march_algorithm=0, repeat=(0.0, 0.0, 0.0), max_steps=None, reflections=0, reflectivity=0.5):
     scene = O.scene_from_bytes(scene_bytes)
     cfg = O.default_config()
     cfg.march_algorithm = march_algorithm
     cfg.repeat[:] = repeat
+    cfg.reflections, cfg.reflectivity = reflections, reflectivity
     if max_steps:
         cfg.max_steps = max_steps
     r = O.render_a(scene, w, h, rot=rot, pos=pos, cfg=cfg)
     out = {"scene": np.frombuffer(scene_bytes, np.uint8), "width": w, "height": h,
            "rot": np.asarray(rot, np.float32), "pos": np.asarray(pos, np.float32), "rgb": r["rgb"],
            "march_algorithm": march_algorithm, "repeat": np.asarray(repeat, np.float32), "max_steps": int(cfg.max_steps),
+           "reflections": reflections, "reflectivity": np.float32(reflectivity),
            "counters": np.array(list(r["counters"].values()), np.uint64)}
     for i, lv in enumerate(r["levels"]):
         out[f"level{i}"] = lv
@@ -44,3 +46,5 @@ if __name__ == "__main__":
     case("path_a_alg1_96x64.npz", bytes(host.default_scene()), 96, 64, host.camera_quat(0.3, -0.1), (0.5, -1.0, 0.2), march_algorithm=1, max_steps=4096)
     case("path_a_alg2_96x64.npz", bytes(host.default_scene()), 96, 64, host.camera_quat(0.3, -0.1), (0.5, -1.0, 0.2), march_algorithm=2, max_steps=4096)
     case("path_a_repeat_96x64.npz", bytes(host.default_scene()), 96, 64, host.camera_quat(0.3, -0.1), (0.5, -1.0, 0.2), repeat=(40.0, 0.0, 40.0), max_steps=4096)
+    # mirror reflections (fragment.glsl:125 TODO; build-defined): two bounces between the spheres of the start-up scene
+    case("path_a_mirror_96x64.npz", bytes(host.default_scene()), 96, 64, host.camera_quat(0.3, -0.1), (0.5, -1.0, 0.2), reflections=2, reflectivity=0.6)

@@ -77,6 +77,10 @@ def test_sketched_variants_and_frames_in_flight(exe, tmp_path):
     cfg.repeat[:] = (40.0, 0.0, 40.0)
     ref = O.render_a(O.default_scene(), 160, 96, cfg=cfg)["rgb"]
     assert np.abs(read_pfm(out) - ref).max() <= 1e-4
+    subprocess.run([exe, "--size", "160x96", "--mirror", "2,0.75", "--out", str(out)], check=True)  # fragment.glsl:125 "TODO: reflection"
+    cfg = O.default_config()
+    cfg.reflections, cfg.reflectivity = 2, 0.75
+    assert np.abs(read_pfm(out) - O.render_a(O.default_scene(), 160, 96, cfg=cfg)["rgb"]).max() <= 1e-4
     a, b = tmp_path / "sync.ppm", tmp_path / "slots.ppm"
     subprocess.run([exe, "--size", "160x96", "--frames", "5", "--out", str(a)], check=True)
     res = subprocess.run([exe, "--size", "160x96", "--frames", "5", "--inflight", "3", "--out", str(b)], check=True, capture_output=True, text=True)

@@ -225,7 +225,7 @@ def test_unorm8():
 
 
 FIXTURES_A = ["path_a_default_64.npz", "path_a_default_turn_96x64.npz", "path_a_cornell_256.npz",
-              "path_a_alg1_96x64.npz", "path_a_alg2_96x64.npz", "path_a_repeat_96x64.npz"]
+              "path_a_alg1_96x64.npz", "path_a_alg2_96x64.npz", "path_a_repeat_96x64.npz", "path_a_mirror_96x64.npz"]
 
 
 def fixture_config(g):
@@ -233,6 +233,8 @@ def fixture_config(g):
     cfg.march_algorithm = int(g["march_algorithm"])
     cfg.repeat[:] = [float(v) for v in g["repeat"]]
     cfg.max_steps = int(g["max_steps"])
+    if "reflections" in g:  # fixtures older than the mirror variant do not carry the fields
+        cfg.reflections, cfg.reflectivity = int(g["reflections"]), float(g["reflectivity"])
     return cfg
 
 
@@ -245,7 +247,9 @@ def test_oracle_matches_committed_fixture(golden_dir, name):
         assert np.array_equal(lv, g[f"level{i}"]), f"level {i}"
     # powf is the only libm call in the path: allow its last-ulp variation across hosts
     np.testing.assert_allclose(r["rgb"], g["rgb"], rtol=0, atol=1e-6)
-    assert list(r["counters"].values()) == g["counters"].tolist()
+    want = g["counters"].tolist()  # fixtures written before a counter existed hold a prefix of today's list; a counter they lack is 0
+    have = list(r["counters"].values())
+    assert have[:len(want)] == want and not any(have[len(want):])
 
 
 # ---- SDF feature growth the author sketched -----------------------------------
@@ -296,3 +300,54 @@ def test_default_scene_matches_reference_listing():
     assert [tuple(o.pos) + (o.size,) for o in s.objs[:4]] == [(5, 5, -1, 3), (5, 4, 10, 6), (-3, 3, -3, 1), (4, -1, 0, 2)]
     assert [m.shine for m in s.mats[:4]] == [1, 10, 1, 1]
     assert bytes(s) == bytes(host.default_scene())
+
+
+# ---- mirror reflections (fragment.glsl:125 "TODO: reflection"; build-defined, oracle.h) ------------------------------
+def test_mirror_reflection_known_answers():
+    """One mirror sphere facing a lit sphere: reflections add exactly weight x (what the reflected point shows when shaded
+    from the mirror point); nothing changes where the mirror ray leaves the scene; reflectivity 0 or specular 0 is the
+    reference image; the second bounce adds to the first."""
+    import copy
+
+    def scene(specular):
+        sc = O.Scene()
+        sc.matCount = sc.objCount = 2
+        sc.lightCount = 1
+        for i, (pos, size, col) in enumerate([((0, 10, 0), 4.0, (0.9, 0.9, 0.9)), ((6, 6, 0), 2.0, (1.0, 0.2, 0.2))]):
+            sc.objs[i].pos[:] = pos
+            sc.objs[i].size = size
+            sc.mats[i].color[:] = col
+            sc.mats[i].diffuse = 1.0
+            sc.mats[i].specular = specular
+            sc.mats[i].shine = 4.0
+            sc.mats[i].ambient = 0.05
+        sc.lights[0].pos[:] = (0, 0, 12)
+        sc.lights[0].color[:] = (2, 2, 2)
+        return sc
+
+    w, h = 96, 96
+    base = O.render_a(scene(1.0), w, h, want_levels=False)
+    cfg = O.default_config()
+    cfg.reflections = 1
+    one = O.render_a(scene(1.0), w, h, cfg=cfg, want_levels=False)
+    d = one["rgb"] - base["rgb"]
+    assert one["counters"]["reflection_rays"] == base["counters"]["hit_pixels"] and base["counters"]["reflection_rays"] == 0
+    changed = np.abs(d).max(-1) > 0
+    assert d.min() >= 0 and changed.sum() > 100  # light is only ever added: the spheres show up in each other
+    on_grey = changed & (np.abs(base["rgb"][..., 0] - base["rgb"][..., 1]) <= 1e-6 * (1 + base["rgb"][..., 0]))  # primary hit = the grey sphere
+    assert on_grey.sum() > 50 and d[on_grey][:, 0].sum() > 4 * d[on_grey][:, 1].sum()  # what the grey mirror shows is the red sphere
+    # pixel (48, 48) looks straight at the grey sphere's pole: the mirror ray returns along -Y, past the camera, to nothing
+    assert np.array_equal(one["rgb"][48, 48], base["rgb"][48, 48])
+    cfg.reflectivity = 0.0
+    assert np.array_equal(O.render_a(scene(1.0), w, h, cfg=cfg, want_levels=False)["rgb"], base["rgb"])
+    cfg.reflectivity = 0.5
+    assert np.array_equal(O.render_a(scene(0.0), w, h, cfg=cfg, want_levels=False)["rgb"], O.render_a(scene(0.0), w, h, want_levels=False)["rgb"])
+    # linear in the weight: reflectivity 0.25 adds half of what 0.5 adds (one bounce, exact powers of two)
+    cfg.reflectivity = 0.25
+    q = O.render_a(scene(1.0), w, h, cfg=cfg, want_levels=False)["rgb"] - base["rgb"]
+    np.testing.assert_allclose(q, d * np.float32(0.5), rtol=0, atol=2e-7)
+    cfg.reflectivity = 0.5
+    cfg.reflections = 2
+    two = O.render_a(scene(1.0), w, h, cfg=cfg, want_levels=False)
+    assert (two["rgb"] >= one["rgb"]).all() and two["counters"]["reflection_rays"] > one["counters"]["reflection_rays"]
+    assert np.isfinite(two["rgb"]).all()
