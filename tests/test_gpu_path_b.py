@@ -398,3 +398,26 @@ def test_two_level_bvh_frames_counts_and_chunk_rebuild(renderer, walker, tmp_pat
     with pytest.raises(R.RtError):
         renderer.set_mesh(v, a, e, bvh_levels=3)
     renderer.resize(64, 64)
+
+
+@pytest.mark.parametrize("yaw,pitch,pos,spp,w,h", [
+    (0.0, 0.0, (0, 0, 0), 3, 131, 77),            # spp that does not divide a wave: packets straddle pixels irregularly
+    (np.pi, 0.0, (0, 30, 0), 2, 96, 64),          # looking along -Y from behind the mesh: every direction sign flipped
+    (np.pi / 2, 0.3, (-14, 15, 0), 1, 100, 60),   # along +X, pitched: the view centre crosses octant boundaries
+    (-np.pi / 2, -0.7, (14, 15, 6), 4, 64, 64),   # along -X, looking down
+    (0.4, 1.2, (0, 14, -11), 2, 80, 48),          # steep upward pitch: rays towards +Z
+    (2.5, -0.2, (1, 15, 2), 5, 70, 40),           # camera INSIDE the mesh volume
+])
+def test_packet_kernel_camera_poses(renderer, yaw, pitch, pos, spp, w, h):
+    """The camera rays go through the wave-uniform packet kernel (one tree walk per 64 paths, lanes of a deviating direction
+    octant in a further pass): frames and ray counts must be the oracle's for views whose packets mix octants, for sample
+    counts that do not tile a wave, for a camera inside the mesh, and must equal the per-lane kernel's (tune_no_packet)."""
+    mesh = scenes.soup_scene(20000, seed=17, edge=0.7)
+    rot = R.camera_quat(yaw, pitch)
+    rgb, ref, st = check_pt(renderer, mesh, w, h, rot=rot, pos=pos, spp=spp, bounces=1, seed=9, sky=(0.3, 0.3, 0.4))
+    assert st["camera_rays"] == w * h * spp
+    per_lane = renderer.render_pt(rot, pos, spp=spp, bounces=1, seed=9, sky=(0.3, 0.3, 0.4), tune_no_packet=1)
+    assert np.array_equal(rgb, per_lane)
+    renderer.render_pt(rot, pos, spp=spp, bounces=1, seed=9, sky=(0.3, 0.3, 0.4), count_traversal=True)
+    ct = renderer.pt_stats()
+    assert ct["packets"] == -(-(-(-w // 64) * -(-h // 64) * 4096 * spp) // 64) and ct["packet_nodes_fetched"] >= ct["packets"]
