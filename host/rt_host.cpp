@@ -7,7 +7,7 @@
 // Everything GPU-side goes through librt_amd.so; this file contains no kernels and no fallbacks.
 //
 //   rt_host [--size WxH] [--yaw R] [--pitch R] [--pos x,y,z] [--move right,forward,up] [--spp N]
-//           [--scene default|soup:N] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm]
+//           [--scene default|soup:N] [--two-level] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm]
 //           [--march 1|2|3] [--repeat x,y,z] [--mirror N[,reflectivity]] [--inflight K]
 #include <chrono>
 #include <cmath>
@@ -106,6 +106,7 @@ int main(int argc, char** argv) {
     float yaw = 0.0f, pitch = 0.0f, pos[3] = {0, 0, 0}, move[3] = {0, 0, 0};
     std::string scene = "default", out = "frame.ppm";
     uint32_t march = 0, inflight = 0, mirror = 0;
+    bool two_level = false;  // soup scenes: top-level BVH over 64 bottom-level chunks (rt_set_mesh_ex)
     float repeat[3] = {0, 0, 0}, reflectivity = 0.5f;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -124,10 +125,11 @@ int main(int argc, char** argv) {
         else if (a == "--march") march = (uint32_t)std::atoi(next());
         else if (a == "--repeat") std::sscanf(next(), "%f,%f,%f", &repeat[0], &repeat[1], &repeat[2]);
         else if (a == "--mirror") std::sscanf(next(), "%u,%f", &mirror, &reflectivity);
+        else if (a == "--two-level") two_level = true;
         else if (a == "--inflight") inflight = (uint32_t)std::atoi(next());
         else {
             std::fprintf(stderr, "usage: rt_host [--size WxH] [--yaw R] [--pitch R] [--pos x,y,z] [--move r,f,u] [--spp N] "
-                                 "[--scene default|soup:N] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm] "
+                                 "[--scene default|soup:N] [--two-level] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm] "
                                  "[--march 1|2|3] [--repeat x,y,z] [--mirror N[,reflectivity]] [--inflight K]\n");
             return 2;
         }
@@ -160,7 +162,8 @@ int main(int argc, char** argv) {
         const uint32_t n = (uint32_t)std::atoi(scene.c_str() + 5);
         std::vector<float> verts, albedo, emission;
         soup_scene(n < 3 ? 3 : n, 1, n >= 500000 ? 0.08f : 0.25f, verts, albedo, emission);
-        if ((rc = rt_set_mesh(ctx, verts.data(), albedo.data(), emission.data(), n < 3 ? 3 : n))) return fail(ctx, "rt_set_mesh", rc);
+        const rt_mesh_options opt{two_level ? 2u : 1u, 0u};
+        if ((rc = rt_set_mesh_ex(ctx, verts.data(), albedo.data(), emission.data(), n < 3 ? 3 : n, &opt))) return fail(ctx, "rt_set_mesh_ex", rc);
         prm.spp = spp;
         prm.bounces = bounces;
         prm.seed = seed;

@@ -65,6 +65,9 @@ def test_soup_scene_path_traced(exe, tmp_path):
     v, a, e = scenes.soup_scene(5000, seed=1, edge=0.25)
     ref, _ = O.TriScene(v, a, e).render(96, 54, spp=2, bounces=1, seed=3, sky=(0.2, 0.2, 0.25))
     assert np.array_equal(read_pfm(out), ref)
+    out2 = tmp_path / "b2.pfm"  # the same frame over the two-level BVH (rt_set_mesh_ex)
+    subprocess.run([exe, "--size", "96x54", "--scene", "soup:5000", "--two-level", "--spp", "2", "--bounces", "1", "--seed", "3", "--out", str(out2)], check=True)
+    assert np.array_equal(read_pfm(out2), ref)
 
 
 def test_sketched_variants_and_frames_in_flight(exe, tmp_path):
