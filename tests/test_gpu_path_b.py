@@ -421,3 +421,27 @@ def test_packet_kernel_camera_poses(renderer, yaw, pitch, pos, spp, w, h):
     renderer.render_pt(rot, pos, spp=spp, bounces=1, seed=9, sky=(0.3, 0.3, 0.4), count_traversal=True)
     ct = renderer.pt_stats()
     assert ct["packets"] == -(-(-(-w // 64) * -(-h // 64) * 4096 * spp) // 64) and ct["packet_nodes_fetched"] >= ct["packets"]
+
+
+@pytest.mark.parametrize("n_tris", [1, 3, 38, 700])
+def test_two_level_bvh_small_meshes(renderer, n_tris):
+    """Two-level builds of meshes too small for 64 chunks (at least four triangles per chunk; one chunk at the limit)."""
+    if n_tris == 38:
+        mesh, pos = scenes.cornell_tri_scene(), (0, 1, 0)
+    elif n_tris == 1:
+        f = np.float32
+        mesh, pos = (np.array([[-1, 5, -1, 1, 5, -1, 0, 5, 1]], f), np.array([[0.5, 0.6, 0.7]], f), np.zeros((1, 3), f)), (0, 0, 0)
+    else:
+        mesh, pos = scenes.soup_scene(n_tris, seed=21, edge=2.0), (0, 0, 0)
+    v, a, e = mesh
+    renderer.set_mesh(v, a, e, bvh_levels=2)
+    st = renderer.pt_stats()
+    assert st["bvh_levels"] == 2 and 1 <= st["blas_chunks"] <= max(1, n_tris // 4)
+    renderer.resize(64, 48)
+    rgb = renderer.render_pt(pos=pos, spp=2, bounces=2, seed=5, sky=(0.4, 0.4, 0.5))
+    ref, ct = O.TriScene(v, a, e).render(64, 48, pos=pos, spp=2, bounces=2, seed=5, sky=(0.4, 0.4, 0.5))
+    st = renderer.pt_stats()
+    assert np.array_equal(rgb, ref) and st["stack_overflow"] == 0
+    assert (st["camera_rays"], st["bounce_rays"], st["shadow_rays"]) == (ct["camera_rays"], ct["bounce_rays"], ct["shadow_rays"])
+    ids = np.concatenate([renderer.mesh_chunk(c) for c in range(st["blas_chunks"])])
+    assert sorted(ids.tolist()) == list(range(len(v)))  # the chunks partition the mesh
