@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -241,6 +241,12 @@ typedef struct rt_pt_params {
                                     (default 0: wave-uniform packet traversal for camera rays) */
     uint32_t tune_sort_rays;     /* tuning: 1 = bounce and shadow rays are sorted inside each 1024-ray workgroup of the shade stage
                                     (LDS counting sort on direction octant + origin cell) before they enter the queues */
+    uint32_t tune_tri_mode;      /* tuning: how the per-lane traversal kernels schedule their ray/triangle tests.  Byte 0: 0 = default,
+                                    1 = inline (every round ends with a triangle phase for the lanes that hold a leaf hit),
+                                    2 = wave-pooled (leaf hits go to a per-wave ring in LDS; the whole wave tests 64 of them at once,
+                                    results merged with a 64-bit LDS minimum on (t, triangle id)).  Pooled mode: byte 1 = groups in the
+                                    ring that trigger a flush (0 = default), byte 2 = rounds a group may wait (0 = default).  Frames do
+                                    not depend on any of it. */
 } rt_pt_params;
 
 typedef struct rt_pt_stats {
@@ -263,6 +269,8 @@ typedef struct rt_pt_stats {
     uint32_t launches_trace_fused;
     uint32_t bvh_levels, blas_chunks, tlas_nodes; /* 1 / 0 / 0 for a single-level mesh */
     float ms_build_blas, ms_build_tlas, ms_build_flatten; /* two-level meshes: phases of the last build or chunk rebuild (bvh_build_ms = all of it) */
+    uint64_t pool_flushes;     /* count_traversal = 1, wave-pooled triangle tests: passes in which a wave tested up to 64 pooled triangles */
+    uint64_t wave_rounds_all;  /* count_traversal = 1: traversal rounds per wave summed over closest-hit AND any-hit launches */
 } rt_pt_stats;
 
 /* How rt_set_mesh_ex builds the acceleration structure.  bvh_levels = 1: one BVH8 over all triangles (rt_set_mesh).

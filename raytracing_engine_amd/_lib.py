@@ -65,7 +65,7 @@ class PtParams(C.Structure):  # rt_pt_params
     _fields_ = [("spp", C.c_uint32), ("bounces", C.c_uint32), ("seed", C.c_uint32), ("sky", C.c_float * 3),
                 ("ray_eps", C.c_float), ("count_traversal", C.c_uint32), ("max_paths", C.c_uint32),
                 ("tune_refill_min", C.c_uint32), ("tune_blocks_per_cu", C.c_uint32), ("tune_lds_stack", C.c_uint32), ("tune_no_overlap", C.c_uint32),
-                ("tune_no_packet", C.c_uint32), ("tune_sort_rays", C.c_uint32)]
+                ("tune_no_packet", C.c_uint32), ("tune_sort_rays", C.c_uint32), ("tune_tri_mode", C.c_uint32)]
 
 
 class MeshOptions(C.Structure):  # rt_mesh_options
@@ -84,7 +84,8 @@ class PtStats(C.Structure):  # rt_pt_stats
                 ("packets", C.c_uint64), ("packet_nodes_fetched", C.c_uint64), ("packet_tris_fetched", C.c_uint64), ("fused_shadow_nodes", C.c_uint64),
                 ("fused_shadow_tris", C.c_uint64), ("fused_shadow_rays", C.c_uint64), ("ms_trace_packet", C.c_float), ("ms_trace_fused", C.c_float),
                 ("launches_trace_fused", C.c_uint32), ("bvh_levels", C.c_uint32), ("blas_chunks", C.c_uint32), ("tlas_nodes", C.c_uint32),
-                ("ms_build_blas", C.c_float), ("ms_build_tlas", C.c_float), ("ms_build_flatten", C.c_float)]
+                ("ms_build_blas", C.c_float), ("ms_build_tlas", C.c_float), ("ms_build_flatten", C.c_float),
+                ("pool_flushes", C.c_uint64), ("wave_rounds_all", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

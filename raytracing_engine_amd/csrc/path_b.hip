@@ -122,6 +122,7 @@ struct Hit {
 
 struct TravCounters {
     uint32_t nodes, tris, overflow;
+    uint32_t flushes = 0;  // TRI_POOL, COUNT: pool_test passes of this wave (wave-uniform)
 };
 
 // A traversal work item (Ylitie et al. 2017): either a node group  x = child_base,
@@ -412,6 +413,86 @@ __global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, P
     if (alive) queue[idx] = pid;
 }
 
+// ---- wave-pooled triangle tests --------------------------------------------------------------------
+// In the per-lane loop a triangle phase runs with the 5-7 lanes that happen to hold a leaf hit (0.12 triangles per node
+// visit on the 1 M soup), at the price of ~65 vector instructions for the whole wave, every round.  Pooled mode takes
+// the phase out of the round: a lane whose node step hit leaf slots appends ONE 8-byte group (tri_base, hit bits,
+// leafmask, owner lane) to a per-wave ring in LDS and keeps traversing; when the ring holds enough groups the whole
+// wave tests one triangle per lane - ray origin / direction of the owner through ds_bpermute, the result merged into
+// the owner's slot with a 64-bit LDS minimum on (t bits, triangle id), which is exactly tri_step's tie-break rule
+// (t > 0, so the float's bits order like the float) - and groups with further hit slots go back to the ring.
+// The owner learns its new tmax / its occlusion after the flush; until then it may enter nodes a tighter tmax would
+// have culled, which never changes a result (boxes are conservative, the hit is a minimum over
+// every triangle tested).  The ring is drained before any lane retires, so a ray's result is complete when it is stored.
+constexpr uint32_t kPoolRing = 128;  // groups; a flush is due at <= 64, a round adds <= 64
+// The pool is read and written by different lanes of ONE wave: DS operations of a wave execute in program order, so no
+// barrier instruction is needed; pool_sync() only keeps the COMPILER from moving LDS accesses across the phase boundaries
+// (the pointers are not volatile: volatile accesses would stay on generic pointers and become flat_* instructions).
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+struct TriPool {
+    lds_u64* ring;  // kPoolRing groups: x = tri_base, y = hit slots 7..0 | leafmask 15..8 | owner lane 21..16
+    lds_u64* best;  // 64 owners: closest = (t bits << 32) | triangle id; any-hit: != 0 = occluded
+    lds_u32* li;    // 64 owners: leaf-order index of the best triangle
+    uint32_t head, count;  // wave-uniform
+};
+__device__ __forceinline__ void pool_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+constexpr unsigned long long kPoolNoHit = (0x7f800000ull << 32) | 0xffffffffull;  // (inf, no id)
+
+__device__ __forceinline__ float lane_read(float v, uint32_t src_lane) {  // ds_bpermute_b32: every lane reads lane src_lane's v
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
+}
+
+// One pass over (at most) the 64 oldest groups of the ring: lane i tests the first pending triangle of group i.
+// Must be called by the whole wave in convergent code.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void pool_test(const float4* __restrict__ tris, const TRay& r, TriPool& P, uint32_t lane, TravCounters& tc) {
+    const uint32_t n = P.count < 64u ? P.count : 64u;
+    const bool has = lane < n;
+    if (COUNT) tc.flushes++;
+    const unsigned long long e = has ? P.ring[(P.head + lane) & (kPoolRing - 1u)] : 0x100ull << 32;
+    const uint32_t ex = (uint32_t)e, ey = (uint32_t)(e >> 32);
+    P.head = uniform(P.head + n);
+    P.count = uniform(P.count - n);
+    const uint32_t bit = (uint32_t)__builtin_ctz(ey);  // lowest pending leaf slot (the idle lanes' dummy has bit 8 set)
+    const uint32_t rest = ey & (ey - 1u);
+    const uint32_t li = ex + (uint32_t)__builtin_popcount((ey >> 8) & 0xffu & ~(0xffffffffu << bit));
+    const uint32_t owner = (ey >> 16) & 63u;
+    const v3 o = mk(lane_read(r.o.x, owner), lane_read(r.o.y, owner), lane_read(r.o.z, owner));
+    const v3 d = mk(lane_read(r.d.x, owner), lane_read(r.d.y, owner), lane_read(r.d.z, owner));
+    bool hit = false;
+    float t = 0.0f;
+    uint32_t id = 0;
+    if (has) {
+        const float4* tp = tris + (size_t)li * 3;
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        if (COUNT) tc.tris++;
+        hit = tri_test(o, d, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t) && t > 0.0f;
+        id = __float_as_uint(c.y);
+    }
+    if (ANY) {
+        if (hit && t < kShadowTmax) P.best[owner] = 1ull;
+    } else {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | id;
+        if (hit) __hip_atomic_fetch_min(&P.best[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        pool_sync();
+        if (hit && P.best[owner] == key) P.li[owner] = li;  // ids are unique: at most one lane per owner sees its own key
+    }
+    // groups with further hit slots go back to the ring
+    const bool more = has && (rest & 0xffu) != 0u;
+    const unsigned long long mm = __ballot(more);
+    if (mm) {
+        const uint32_t pos = P.head + P.count + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+        if (more) P.ring[pos & (kPoolRing - 1u)] = ((unsigned long long)rest << 32) | ex;
+        P.count = uniform(P.count + (uint32_t)__popcll(mm));
+    }
+    pool_sync();
+}
+
 // ---- trace ----------------------------------------------------------------------------------------
 // Persistent waves with per-lane refill.  Traversal lengths are heavy-tailed (a ray may end after 3
 // nodes or after 500), so a wave that waits for its slowest ray idles most lanes.  Instead every
@@ -423,10 +504,24 @@ __global__ __launch_bounds__(kAppendThreads) void pt_generate(const PtFrame f, P
 // Between two refill checks every lane visits one node and tests up to `kTrisPerRound` triangles.
 constexpr int kTrisPerRound = 1;
 
-template <bool ANY, bool COUNT>
+// How the triangle tests of the per-lane kernels are scheduled (rt_pt_params.tune_tri_mode):
+//   TRI_INLINE  every round ends with a triangle phase for the lanes that hold a leaf hit (rounds 1 and 2 of the build)
+//   TRI_POOL    wave-pooled tests: leaf hits go to a per-wave LDS ring, the wave tests 64 of them at once (above)
+//   TRI_DEFER   postponed tests: a lane parks up to two leaf-hit groups in registers and keeps visiting nodes; the triangle
+//               phase runs when enough lanes hold a group (or enough of them can do nothing else)
+enum { TRI_INLINE = TRI_MODE_INLINE, TRI_POOL = TRI_MODE_POOL, TRI_DEFER = TRI_MODE_DEFER };
+
+struct PoolMem {  // LDS of one wave's pool (TRI_POOL kernels only)
+    lds_u64* ring;
+    lds_u64* best;
+    lds_u32* li;
+};
+
+template <bool ANY, bool COUNT, int MODE>
 __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st, const uint32_t* __restrict__ queue,
                                             const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
                                             unsigned long long* __restrict__ stats, TravStack& stk, const uint8_t* perm_lut, uint32_t refill_min,
+                                            const PoolMem& pm, uint32_t tri_cfg /* TRI_POOL: byte 0 = groups that trigger a flush, byte 1 = rounds a group may wait */,
                                             uint32_t shadow_stat /* word of the shadow-ray node counter: 4 alone, 11 inside the fused launch */ = 4u) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -437,7 +532,7 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
 
     TRay r = make_tray(mk(0.0f, 0.0f, 0.0f), mk(0.0f, 1.0f, 0.0f), 0.0f);
     Hit best{0.0f, -1, 0u};
-    Group G{0u, 0u}, T{0u, 0u};
+    Group G{0u, 0u}, T{0u, 0u}, T2{0u, 0u};  // T2: TRI_DEFER's second parking slot
     uint32_t slot = 0;  // closest: path id; any-hit: shadow-queue index
     bool has_ray = false, occluded = false;
     bool exhausted = n == 0;  // wave-uniform: every stream of the queue has been found dry
@@ -446,10 +541,33 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
     uint32_t rounds = 0, alive_rounds = 0;                // COUNT only
     bool alive = false;       // this lane still has traversal work for its ray
 
+    // TRI_POOL state (all wave-uniform)
+    TriPool P{pm.ring, pm.best, pm.li, 0u, 0u};
+    const lds_u32* best32 = reinterpret_cast<const lds_u32*>(pm.best);
+    // TRI_POOL: groups in the ring that trigger a flush / rounds a group may wait;  TRI_DEFER: holding lanes / stuck lanes that trigger the phase
+    const uint32_t flush_at = (tri_cfg & 0xffu) ? ((tri_cfg & 0xffu) < 64u ? (tri_cfg & 0xffu) : 64u) : (MODE == TRI_DEFER ? 32u : 40u);
+    const uint32_t wait_max = ((tri_cfg >> 8) & 0xffu) ? ((tri_cfg >> 8) & 0xffu) : (MODE == TRI_DEFER ? 8u : 6u);
+    uint32_t waited = 0;
+    bool flushed = false;
+
     for (;;) {
         const unsigned long long idle = __ballot(!alive);
         if (idle == ~0ull || (!exhausted && (uint32_t)__popcll(idle) >= refill_min)) {
+            if (MODE == TRI_POOL) {  // a ray's result is complete only when none of its triangles is pending
+                while (P.count) {
+                    pool_test<ANY, COUNT>(sc.tris, r, P, lane, tc);
+                    flushed = true;
+                }
+                waited = 0;
+            }
             if (!alive && has_ray) {  // retire
+                if (MODE == TRI_POOL) {
+                    if (ANY) occluded = best32[2u * lane] != 0u;
+                    else {
+                        best.t = __uint_as_float(best32[2u * lane + 1u]);
+                        best.li = (int)pm.li[lane];
+                    }
+                }
                 if (ANY) {
                     if (!occluded) {
                         const uint32_t pid = __float_as_uint(st.sh_o[slot].w);
@@ -485,16 +603,22 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
                         r = make_tray(mk(so.x, so.y, so.z), mk(sd.x, sd.y, sd.z), kShadowTmax);
                         slot = i;
                         occluded = false;
+                        if (MODE == TRI_POOL) pm.best[lane] = 0ull;
                     } else {
                         slot = queue[i];
                         const float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
                         r = make_tray(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), __builtin_inff());
                         best = Hit{__builtin_inff(), -1, 0xffffffffu};
+                        if (MODE == TRI_POOL) {
+                            pm.best[lane] = kPoolNoHit;
+                            pm.li[lane] = 0xffffffffu;
+                        }
                     }
                     has_ray = true;
                     alive = true;
                     G = root_group();
                     T = Group{0u, 0u};
+                    T2 = Group{0u, 0u};
                     stk.sp = 0;
                 }
             }
@@ -504,21 +628,92 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
             rounds++;
             alive_rounds += (uint32_t)__popcll(__ballot(alive));
         }
-        // node phase: lanes without pending triangles visit their next node
-        if (alive && !has_tris(T)) {
-            if (!has_nodes(G)) {
-                if (stk.sp) G = stk.pop();
-                else alive = false;
+        if (MODE == TRI_POOL) {
+            if (flushed) {  // owners pick up what the pool found for them (wave-uniform branch)
+                flushed = false;
+                if (ANY) {
+                    if (alive && best32[2u * lane] != 0u) alive = false;  // occluded: the ray is done
+                } else if (alive) {
+                    r.tmax = __uint_as_float(best32[2u * lane + 1u]);
+                }
             }
-            if (alive) node_step<COUNT>(sc.nodes, perm_lut, r, G, T, stk, tc);
-        }
-        // triangle phase
+            // node phase: every lane with traversal work visits its next node
+            T.y = 0u;
+            if (alive) {
+                if (!has_nodes(G)) {
+                    if (stk.sp) G = stk.pop();
+                    else alive = false;
+                }
+                if (alive) node_step<COUNT>(sc.nodes, perm_lut, r, G, T, stk, tc);
+            }
+            // leaf hits of this round -> the ring (ballot + prefix popcount, no atomic: head / count are wave-uniform)
+            const bool add = has_tris(T);
+            const unsigned long long am = __ballot(add);
+            if (am) {
+                const uint32_t pos = P.head + P.count + (uint32_t)__popcll(am & lt_mask);
+                if (add) P.ring[pos & (kPoolRing - 1u)] = ((unsigned long long)(T.y | (lane << 16)) << 32) | T.x;
+                P.count = uniform(P.count + (uint32_t)__popcll(am));
+                pool_sync();
+            }
+            waited = P.count ? waited + 1u : 0u;
+            if (P.count >= flush_at || waited >= wait_max) {
+                pool_test<ANY, COUNT>(sc.tris, r, P, lane, tc);
+                flushed = true;
+                waited = 0;
+            }
+        } else if (MODE == TRI_DEFER) {
+            // node phase: a lane visits its next node as long as it has somewhere to park a leaf-hit group
+            bool stuck = false;  // holds a group and cannot visit a node: out of nodes, or both parking slots taken
+            if (alive) {
+                if (!has_nodes(G) && stk.sp) G = stk.pop();
+                if (!has_nodes(G)) {
+                    if (has_tris(T)) stuck = true;
+                    else alive = false;  // no nodes left, nothing parked: the ray is done
+                } else if (has_tris(T2)) {
+                    stuck = true;
+                } else {
+                    Group N{0u, 0u};
+                    node_step<COUNT>(sc.nodes, perm_lut, r, G, N, stk, tc);
+                    if (has_tris(N)) {
+                        if (has_tris(T)) T2 = N;
+                        else T = N;
+                    }
+                }
+            }
+            // triangle phase: one test per holding lane, when enough lanes hold a group or enough of them are stuck
+            const unsigned long long hold = __ballot(alive && has_tris(T));
+            const unsigned long long stuck_m = __ballot(stuck);
+            const uint32_t n_hold = (uint32_t)__popcll(hold), n_stuck = (uint32_t)__popcll(stuck_m);
+            if (n_hold >= flush_at || n_stuck >= wait_max || (n_stuck != 0u && n_stuck == (uint32_t)__popcll(__ballot(alive)))) {
+                if (alive && has_tris(T)) {
+                    if (tri_step<ANY, COUNT>(sc.tris, r, best, T, tc)) {
+                        occluded = true;
+                        alive = false;
+                    }
+                    if (!has_tris(T)) {
+                        T = T2;
+                        T2 = Group{0u, 0u};
+                    }
+                }
+                if (COUNT) tc.flushes++;
+            }
+        } else {
+            // node phase: lanes without pending triangles visit their next node
+            if (alive && !has_tris(T)) {
+                if (!has_nodes(G)) {
+                    if (stk.sp) G = stk.pop();
+                    else alive = false;
+                }
+                if (alive) node_step<COUNT>(sc.nodes, perm_lut, r, G, T, stk, tc);
+            }
+            // triangle phase
 #pragma unroll 1
-        for (int it = 0; it < tris_per_round; it++) {
-            if (alive && has_tris(T)) {
-                if (tri_step<ANY, COUNT>(sc.tris, r, best, T, tc)) {
-                    occluded = true;
-                    alive = false;
+            for (int it = 0; it < tris_per_round; it++) {
+                if (alive && has_tris(T)) {
+                    if (tri_step<ANY, COUNT>(sc.tris, r, best, T, tc)) {
+                        occluded = true;
+                        alive = false;
+                    }
                 }
             }
         }
@@ -535,6 +730,8 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
                 atomicAdd(&stats[6], (unsigned long long)rounds);
                 atomicAdd(&stats[7], (unsigned long long)alive_rounds);
             }
+            atomicAdd(&stats[13], (unsigned long long)tc.flushes);
+            atomicAdd(&stats[14], (unsigned long long)rounds);
             atomicAdd(&stats[ANY ? shadow_stat : 0u], a);
             atomicAdd(&stats[ANY ? shadow_stat + 1u : 1u], b);
         }
@@ -542,34 +739,55 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
     if (tc.overflow) atomicOr((unsigned int*)&stats[2], 1u);
 }
 
-template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(256, 8) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
+// LDS of a 256-thread workgroup of the per-lane kernels: the traversal stacks (dynamic), the octant table and, for TRI_POOL
+// kernels, four pools of 1.75 KiB.
+template <int MODE>
+struct PoolLds {
+    __device__ __forceinline__ PoolMem get(uint32_t) { return PoolMem{nullptr, nullptr, nullptr}; }
+};
+template <>
+struct PoolLds<TRI_POOL> {
+    unsigned long long ring[4][kPoolRing];
+    unsigned long long best[4][64];
+    uint32_t li[4][64];
+    __device__ __forceinline__ PoolMem get(uint32_t wave) {
+        return PoolMem{(lds_u64*)ring[wave], (lds_u64*)best[wave], (lds_u32*)li[wave]};
+    }
+};
+constexpr uint32_t kPoolLdsBytes = 4u * (kPoolRing * 8u + 64u * 8u + 64u * 4u);
+constexpr int kPoolWaves = 7;  // waves per SIMD the TRI_POOL / TRI_DEFER kernels are compiled for (72 VGPRs; the default stack split leaves room for seven workgroups per CU anyway)
+
+template <bool ANY, bool COUNT, int MODE>
+__global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : kPoolWaves) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
                                                 const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
-                                                unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min) {
+                                                unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min, uint32_t tri_cfg) {
     extern __shared__ unsigned long long lds_stack[];  // sk.lds_cap x 256 entries
     __shared__ uint8_t perm_lut[2048];
+    __shared__ PoolLds<MODE> pool;
     build_perm_lut(perm_lut);
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
     TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
-    trace_queue<ANY, COUNT>(sc, st, queue, count_ptr, head, stats, stk, perm_lut, refill_min);
+    trace_queue<ANY, COUNT, MODE>(sc, st, queue, count_ptr, head, stats, stk, perm_lut, refill_min, pool.get(threadIdx.x >> 6), tri_cfg);
 }
 
 // closest-hit rays of depth d + 1 and the shadow rays of depth d in ONE persistent launch: the two are independent (the
 // shadow rays only add to the paths' radiance, the closest-hit rays only read rays), so every wave first pulls from the
 // closest-hit queue - the frame's critical path: shade(d + 1) waits for it - and moves on to the shadow queue when that one
 // is dry, instead of leaving the machine to the few long rays of a launch's tail.  One tail per bounce instead of two.
-template <bool COUNT>
-__global__ __launch_bounds__(256, 8) void pt_trace_fused(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
+template <bool COUNT, int MODE>
+__global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : kPoolWaves) void pt_trace_fused(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
                                                       const uint32_t* __restrict__ closest_count, uint32_t* __restrict__ closest_head,
                                                       const uint32_t* __restrict__ shadow_count, uint32_t* __restrict__ shadow_head,
-                                                      unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min) {
+                                                      unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min, uint32_t tri_cfg) {
     extern __shared__ unsigned long long lds_stack[];
     __shared__ uint8_t perm_lut[2048];
+    __shared__ PoolLds<MODE> pool;
     build_perm_lut(perm_lut);
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
     TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
-    trace_queue<false, COUNT>(sc, st, queue, closest_count, closest_head, stats, stk, perm_lut, refill_min);
-    trace_queue<true, COUNT>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, perm_lut, refill_min, 11u);
+    const PoolMem pm = pool.get(threadIdx.x >> 6);
+    trace_queue<false, COUNT, MODE>(sc, st, queue, closest_count, closest_head, stats, stk, perm_lut, refill_min, pm, tri_cfg);
+    trace_queue<true, COUNT, MODE>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, perm_lut, refill_min, pm, tri_cfg, 11u);
 }
 
 // ---- packet trace (camera rays) ---------------------------------------------------------------------
@@ -901,33 +1119,58 @@ int launch_pt_generate(Ctx* c, const PtFrame& f, const PtState& st, uint32_t* qu
 }
 
 int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head,
-                    unsigned long long* stats, bool any_hit, bool count, uint32_t grid, const StackCfg& stack_cap, uint32_t refill_min) {
+                    unsigned long long* stats, bool any_hit, bool count, uint32_t grid, const StackCfg& stack_cap, uint32_t refill_min, uint32_t tri_mode,
+                    uint32_t tri_cfg) {
     if (stack_cap.lds_cap < 1 || stack_cap.lds_cap > 160 || (size_t)grid * 256u > stack_cap.spill_stride)
         return c->fail(RT_ERR_INVALID, "bad traversal stack configuration");
     const dim3 g(grid), b(256);
     const size_t lds = (size_t)stack_cap.lds_cap * 256 * sizeof(unsigned long long);
+#define RT_LAUNCH_TRACE(ANY, COUNT, MODE) \
+    hipLaunchKernelGGL((pt_trace<ANY, COUNT, MODE>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min, tri_cfg)
+#define RT_LAUNCH_TRACE_MODE(ANY, COUNT)                         \
+    do {                                                         \
+        if (tri_mode == TRI_POOL) RT_LAUNCH_TRACE(ANY, COUNT, TRI_POOL); \
+        else if (tri_mode == TRI_DEFER) RT_LAUNCH_TRACE(ANY, COUNT, TRI_DEFER); \
+        else RT_LAUNCH_TRACE(ANY, COUNT, TRI_INLINE);            \
+    } while (0)
     if (any_hit) {
-        if (count) hipLaunchKernelGGL((pt_trace<true, true>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
-        else hipLaunchKernelGGL((pt_trace<true, false>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
+        if (count) RT_LAUNCH_TRACE_MODE(true, true);
+        else RT_LAUNCH_TRACE_MODE(true, false);
     } else {
-        if (count) hipLaunchKernelGGL((pt_trace<false, true>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
-        else hipLaunchKernelGGL((pt_trace<false, false>), g, b, lds, c->stream, sc, st, queue, count_ptr, head, stats, stack_cap, refill_min);
+        if (count) RT_LAUNCH_TRACE_MODE(false, true);
+        else RT_LAUNCH_TRACE_MODE(false, false);
     }
+#undef RT_LAUNCH_TRACE_MODE
+#undef RT_LAUNCH_TRACE
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
 
 int launch_pt_trace_fused(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t* queue, const uint32_t* closest_count, uint32_t* closest_head,
                           const uint32_t* shadow_count, uint32_t* shadow_head, unsigned long long* stats, bool count, uint32_t grid,
-                          const StackCfg& stack_cap, uint32_t refill_min) {
+                          const StackCfg& stack_cap, uint32_t refill_min, uint32_t tri_mode, uint32_t tri_cfg) {
     if (stack_cap.lds_cap < 1 || stack_cap.lds_cap > 160 || (size_t)grid * 256u > stack_cap.spill_stride)
         return c->fail(RT_ERR_INVALID, "bad traversal stack configuration");
     const size_t lds = (size_t)stack_cap.lds_cap * 256 * sizeof(unsigned long long);
-    if (count) hipLaunchKernelGGL(pt_trace_fused<true>, dim3(grid), dim3(256), lds, c->stream, sc, st, queue, closest_count, closest_head, shadow_count, shadow_head, stats, stack_cap, refill_min);
-    else hipLaunchKernelGGL(pt_trace_fused<false>, dim3(grid), dim3(256), lds, c->stream, sc, st, queue, closest_count, closest_head, shadow_count, shadow_head, stats, stack_cap, refill_min);
+#define RT_LAUNCH_FUSED(COUNT, MODE)                                                                                                                  \
+    hipLaunchKernelGGL((pt_trace_fused<COUNT, MODE>), dim3(grid), dim3(256), lds, c->stream, sc, st, queue, closest_count, closest_head, shadow_count, \
+                       shadow_head, stats, stack_cap, refill_min, tri_cfg)
+    if (tri_mode == TRI_POOL) {
+        if (count) RT_LAUNCH_FUSED(true, TRI_POOL);
+        else RT_LAUNCH_FUSED(false, TRI_POOL);
+    } else if (tri_mode == TRI_DEFER) {
+        if (count) RT_LAUNCH_FUSED(true, TRI_DEFER);
+        else RT_LAUNCH_FUSED(false, TRI_DEFER);
+    } else {
+        if (count) RT_LAUNCH_FUSED(true, TRI_INLINE);
+        else RT_LAUNCH_FUSED(false, TRI_INLINE);
+    }
+#undef RT_LAUNCH_FUSED
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
+
+uint32_t pt_pool_lds_bytes(uint32_t tri_mode) { return tri_mode == TRI_POOL ? kPoolLdsBytes : 0u; }
 
 int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count) {
     const dim3 g((f.n_paths + 255u) / 256u), b(256);

@@ -21,6 +21,7 @@ namespace {
 constexpr uint64_t kMaxPathsInFlight = 1ull << 25;  // 33.5 M paths = 4.3 GB of wavefront state
 constexpr uint32_t kMaxBounces = 15;
 constexpr size_t kStatWords = 16;  // device-side traversal statistics (path_b.hip)
+constexpr uint32_t kDefaultTriMode = rt::TRI_MODE_INLINE;  // rt_pt_params.tune_tri_mode = 0
 constexpr float kCameraReach = 32.0f;  // camera |coordinate| limit in units of the mesh's largest |coordinate| (render_pt_common)
 
 int bind(Ctx* c) {
@@ -98,13 +99,13 @@ int ensure_wavefront(Ctx* c, uint64_t n_paths, uint64_t n_slots) {
 // Traversal stack + persistent grid.  The first lds_cap entries of every lane's stack live in LDS
 // (8-byte entries: 2 x lds_cap KiB per 256-thread workgroup, next to the kernel's 2 KiB octant table), which bounds residency at floor(160 KiB / that) workgroups
 // per CU, 8 at most (32 waves per CU); the rest of the builder's worst case spills to global memory.
-int stack_config(Ctx* c, uint32_t tune_lds, uint32_t tune_blocks, uint64_t n_paths, rt::StackCfg* sk, uint32_t* grid) {
+int stack_config(Ctx* c, uint32_t tune_lds, uint32_t tune_blocks, uint64_t n_paths, rt::StackCfg* sk, uint32_t* grid, uint32_t extra_lds_bytes = 0) {
     PtData& pt = c->pt;
     const uint32_t need = std::max<uint32_t>(pt.stack_need, 1u);
     // default: up to ten entries in LDS - the whole stack of the 1 M-triangle tree (depth 9) - at seven workgroups per CU
     // (measured 1 % ahead of eight entries at eight workgroups)
     const uint32_t lds_cap = std::min<uint32_t>(need, tune_lds ? std::min<uint32_t>(tune_lds, 78u) : 10u);
-    const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(8u, 160u / (2u * lds_cap + 2u)));  // 2 KiB per entry per workgroup + the 2 KiB octant table
+    const uint32_t fit = std::max<uint32_t>(1u, std::min<uint32_t>(8u, (160u * 1024u) / (2048u * lds_cap + 2048u + extra_lds_bytes)));  // 2 KiB per entry per workgroup + the 2 KiB octant table (+ the triangle pools)
     // Few paths (a rank's small share of a frame): fewer resident waves.  Every lane of the grid takes a ray
     // at once, so with ~2 rays per lane the rays in flight span half the frame instead of a compact window
     // and the short launches are all ramp and tail; about four rays per lane and more measured best
@@ -213,7 +214,11 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     const bool count = prm->count_traversal != 0;
     rt::StackCfg stack_cap{};
     uint32_t grid_persistent = 0;
-    if (int rc = stack_config(c, prm->tune_lds_stack, prm->tune_blocks_per_cu, n_slots * spp_batch, &stack_cap, &grid_persistent)) return rc;
+    // triangle-test schedule of the per-lane kernels: byte 0 = mode (0 = default), bytes 1-2 = the pool's flush parameters
+    const uint32_t tri_mode = (prm->tune_tri_mode & 0xffu) ? (prm->tune_tri_mode & 0xffu) : kDefaultTriMode;
+    if (tri_mode < rt::TRI_MODE_INLINE || tri_mode > rt::TRI_MODE_DEFER) return c->fail(RT_ERR_INVALID, "tune_tri_mode %u (0 .. 3)", tri_mode);
+    const uint32_t tri_cfg = prm->tune_tri_mode >> 8;
+    if (int rc = stack_config(c, prm->tune_lds_stack, prm->tune_blocks_per_cu, n_slots * spp_batch, &stack_cap, &grid_persistent, rt::pt_pool_lds_bytes(tri_mode))) return rc;
     // low byte: idle lanes that trigger a refill; next byte (tuning): inner steps per round
     const uint32_t refill_min = (prm->tune_refill_min & 0xffu ? std::min<uint32_t>(prm->tune_refill_min & 0xffu, 64u) : 24u) | (prm->tune_refill_min & 0xff00u);
     const uint32_t grid_stride = (uint32_t)c->n_cus * 2u;  // 1024-thread workgroups, grid-stride
@@ -280,12 +285,12 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
                 if (int rc = rt::launch_pt_trace_packet(c, sc, f, pt.st, pt.d_stats, count)) return rc;
             } else if (shadow_deferred) {  // closest(d) + shadow(d - 1): ctr_d holds both the closest count of depth d and the shadow count of depth d - 1
                 if (int rc = rt::launch_pt_trace_fused(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, ctr_d + rt::PT_CTR_SHADOW_COUNT,
-                                                       ctr_d + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, count, grid_persistent, stack_cap, refill_min))
+                                                       ctr_d + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, count, grid_persistent, stack_cap, refill_min, tri_mode, tri_cfg))
                     return rc;
                 shadow_deferred = false;
                 launches_shadow++;
                 launches_fused++;
-            } else if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent, stack_cap, refill_min)) {
+            } else if (int rc = rt::launch_pt_trace(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, pt.d_stats, false, count, grid_persistent, stack_cap, refill_min, tri_mode, tri_cfg)) {
                 return rc;
             }
             tm.end();
@@ -313,7 +318,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
                     c->stream = c->aux_stream;
                 }
                 tm.begin(3);
-                int rc = rt::launch_pt_trace(c, sc, pt.st, nullptr, ctr_n + rt::PT_CTR_SHADOW_COUNT, ctr_n + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, true, count, grid_persistent, sk2, refill_min);
+                int rc = rt::launch_pt_trace(c, sc, pt.st, nullptr, ctr_n + rt::PT_CTR_SHADOW_COUNT, ctr_n + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, true, count, grid_persistent, sk2, refill_min, tri_mode, tri_cfg);
                 tm.end();
                 if (overlap) {
                     hipError_t e = rc ? hipSuccess : hipEventRecord(pt.ev_shadowed, c->aux_stream);
@@ -377,6 +382,8 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         pt.stats.wave_rounds = st[6];
         pt.stats.alive_lane_rounds = st[7];
         pt.stats.packets = st[8];
+        pt.stats.pool_flushes = st[13];
+        pt.stats.wave_rounds_all = st[14];
         pt.stats.stack_overflow = (uint32_t)st[2];
         RT_HIP(c, hipEventElapsedTime(&pt.stats.ms_total, c->ev_begin, c->ev_end));
         float sums[7] = {};
@@ -459,6 +466,7 @@ int rt_default_pt_params(rt_pt_params* p) {
     p->tune_no_overlap = 0;
     p->tune_no_packet = 0;
     p->tune_sort_rays = 0;
+    p->tune_tri_mode = 0;
     return RT_OK;
 }
 

@@ -139,6 +139,8 @@ struct PtScene {
     uint32_t n_tris;
 };
 
+enum { TRI_MODE_INLINE = 1, TRI_MODE_POOL = 2, TRI_MODE_DEFER = 3 };  // rt_pt_params.tune_tri_mode, byte 0 (path_b.hip: TRI_INLINE, TRI_POOL)
+
 struct StackCfg {  // per-lane traversal stack of 8-byte entries: lds_cap in LDS, then spill_cap in global memory
     unsigned long long* spill;  // spill_cap x spill_stride entries, entry-major
     size_t spill_stride;  // = threads of the persistent grid
@@ -274,10 +276,12 @@ int launch_to_rgba8(Ctx* c, const float* rgb, uint8_t* rgba, uint64_t n_pixels);
 // path_b.hip
 int launch_pt_generate(Ctx* c, const PtFrame& f, const PtState& st, uint32_t* queue, uint32_t* ctr);
 int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr, uint32_t* head,
-                    unsigned long long* stats, bool any_hit, bool count, uint32_t grid, const StackCfg& stack_cap, uint32_t refill_min);
+                    unsigned long long* stats, bool any_hit, bool count, uint32_t grid, const StackCfg& stack_cap, uint32_t refill_min, uint32_t tri_mode,
+                    uint32_t tri_cfg);
 int launch_pt_trace_fused(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t* queue, const uint32_t* closest_count, uint32_t* closest_head,
                           const uint32_t* shadow_count, uint32_t* shadow_head, unsigned long long* stats, bool count, uint32_t grid,
-                          const StackCfg& stack_cap, uint32_t refill_min);
+                          const StackCfg& stack_cap, uint32_t refill_min, uint32_t tri_mode, uint32_t tri_cfg);
+uint32_t pt_pool_lds_bytes(uint32_t tri_mode);  // static LDS a 256-thread workgroup of the per-lane kernels needs beyond the stacks and the octant table
 int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count);
 int launch_pt_shade(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr,
                     uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid, bool sort_rays);

@@ -319,7 +319,7 @@ class Renderer:
         self._check(self._lib.rt_update_mesh_chunk(self._ctx, chunk, _fptr(verts)))
 
     def pt_params(self, spp=4, bounces=1, seed=1, sky=(0.0, 0.0, 0.0), ray_eps=1e-3, count_traversal=False, max_paths=0, tune_refill_min=0,
-                  tune_blocks_per_cu=0, tune_lds_stack=0, tune_no_overlap=0, tune_no_packet=0, tune_sort_rays=0):
+                  tune_blocks_per_cu=0, tune_lds_stack=0, tune_no_overlap=0, tune_no_packet=0, tune_sort_rays=0, tune_tri_mode=0):
         p = PtParams()
         self._lib.rt_default_pt_params(C.byref(p))
         p.spp, p.bounces, p.seed, p.ray_eps, p.count_traversal, p.max_paths = spp, bounces, seed, ray_eps, int(count_traversal), max_paths
@@ -327,6 +327,7 @@ class Renderer:
         p.tune_no_overlap = tune_no_overlap
         p.tune_no_packet = tune_no_packet
         p.tune_sort_rays = tune_sort_rays
+        p.tune_tri_mode = tune_tri_mode
         p.sky[:] = [float(np.float32(x)) for x in sky]
         return p
 

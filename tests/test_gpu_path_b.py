@@ -222,23 +222,42 @@ def test_shadow_overlap_does_not_change_results(renderer):
     assert st1["launches_trace_closest"] == 4 and st1["launches_trace_shadow"] == 4
 
 
+_KNOB_SCENE = {}
+
+
+def _knob_scene():
+    """The knob tests' scene and the ORACLE's frame + ray counts for it (computed once per session)."""
+    if not _KNOB_SCENE:
+        v, a, e = scenes.soup_scene(30000, seed=9, edge=0.6)
+        ref, ct = O.TriScene(v, a, e).render(160, 96, spp=2, bounces=2, seed=5, sky=(0.2, 0.2, 0.25))
+        _KNOB_SCENE.update(mesh=(v, a, e), ref=ref, ct=ct)
+    return _KNOB_SCENE
+
+
 @pytest.mark.parametrize("knobs", [dict(tune_refill_min=1), dict(tune_refill_min=64), dict(tune_refill_min=8 | (3 << 8)), dict(tune_blocks_per_cu=1),
                                    dict(tune_blocks_per_cu=3, tune_lds_stack=2), dict(tune_lds_stack=1), dict(tune_lds_stack=40),
-                                   dict(tune_no_packet=1), dict(tune_sort_rays=1), dict(tune_sort_rays=1, tune_no_packet=1, tune_no_overlap=1)])
+                                   dict(tune_no_packet=1), dict(tune_sort_rays=1), dict(tune_sort_rays=1, tune_no_packet=1, tune_no_overlap=1),
+                                   dict(tune_no_overlap=1), dict(tune_no_overlap=2),
+                                   dict(tune_tri_mode=1), dict(tune_tri_mode=2), dict(tune_tri_mode=2 | (1 << 8) | (1 << 16)),
+                                   dict(tune_tri_mode=2 | (64 << 8) | (255 << 16)), dict(tune_tri_mode=2 | (7 << 8) | (3 << 16), tune_refill_min=1),
+                                   dict(tune_tri_mode=2, tune_no_packet=1, tune_no_overlap=1, tune_lds_stack=1),
+                                   dict(tune_tri_mode=2, tune_no_overlap=2, tune_refill_min=64), dict(tune_tri_mode=2, tune_sort_rays=1, tune_blocks_per_cu=1),
+                                   dict(tune_tri_mode=3), dict(tune_tri_mode=3 | (1 << 8) | (1 << 16)), dict(tune_tri_mode=3 | (64 << 8) | (64 << 16)),
+                                   dict(tune_tri_mode=3 | (64 << 8) | (255 << 16), tune_refill_min=1), dict(tune_tri_mode=3 | (16 << 8) | (2 << 16), tune_no_packet=1, tune_no_overlap=1, tune_lds_stack=1),
+                                   dict(tune_tri_mode=3, tune_no_overlap=2, tune_refill_min=64)])
 def test_scheduling_knobs_do_not_change_the_frame(renderer, knobs):
-    """Refill threshold, triangle tests per round, resident workgroups, LDS / spill split of the traversal
-    stack: pure scheduling, so the frame and the ray counts must be identical to the default's."""
-    v, a, e = scenes.soup_scene(30000, seed=9, edge=0.6)
-    renderer.set_mesh(v, a, e)
+    """Refill threshold, triangle tests per round, inline / wave-pooled triangle tests and the pool's flush rule, resident
+    workgroups, LDS / spill split of the traversal stack, rays sorted in LDS, launch overlap: pure scheduling, so the frame and
+    the ray counts must equal the ORACLE's (not just the default configuration's)."""
+    k = _knob_scene()
+    renderer.set_mesh(*k["mesh"])
     renderer.resize(160, 96)
-    base = renderer.render_pt(spp=2, bounces=2, seed=5, sky=(0.2, 0.2, 0.25))
-    st0 = renderer.pt_stats()
     got = renderer.render_pt(spp=2, bounces=2, seed=5, sky=(0.2, 0.2, 0.25), **knobs)
-    st1 = renderer.pt_stats()
-    assert np.array_equal(base, got)
-    assert st1["stack_overflow"] == 0
-    for k in ("camera_rays", "bounce_rays", "shadow_rays"):
-        assert st0[k] == st1[k]
+    st = renderer.pt_stats()
+    assert np.array_equal(got, k["ref"]), f"{np.count_nonzero(got != k['ref'])} values differ from the oracle's frame"
+    assert st["stack_overflow"] == 0
+    for c in ("camera_rays", "bounce_rays", "shadow_rays"):
+        assert st[c] == k["ct"][c], c
 
 
 def test_queue_streams_cover_every_entry_exactly_once(renderer):

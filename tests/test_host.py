@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"librt_amd.so does not export {n}"
         assert n in _lib.PROTOTYPES, f"python binding lacks a prototype for {n}"
     assert sorted(_lib.PROTOTYPES) == names
-    assert lib.rt_abi_version() == 3
+    assert lib.rt_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header(tmp_path):
