@@ -274,14 +274,14 @@ typedef struct rt_pt_stats {
 } rt_pt_stats;
 
 /* How rt_set_mesh_ex builds the acceleration structure.  bvh_levels = 1: one BVH8 over all triangles (rt_set_mesh).
- * bvh_levels = 2 (BASELINE.json configs[2] "2-level BVH"): the triangles are cut into blas_chunks runs of their
- * centroids' Morton order (0 = 64), every run gets a bottom-level BVH8 of its own, a top-level BVH8 is built over the
- * chunk boxes, and both levels are flattened into the one node array the kernels traverse.  Frames are identical either
+ * bvh_levels = 2 (BASELINE.json configs[2] "2-level BVH"): the triangles are cut into blas_chunks chunks (0 = 64), the
+ * leaves of a top-down binned-SAH split that always divides the fullest leaf, every chunk gets a bottom-level BVH8 of its
+ * own, a top-level BVH8 is built over the chunk boxes, and both levels are flattened into the one node array the kernels traverse.  Frames are identical either
  * way (results do not depend on the tree); the two-level mesh can have one chunk's vertices replaced and only that
  * chunk rebuilt (rt_update_mesh_chunk). */
 typedef struct rt_mesh_options {
     uint32_t bvh_levels;  /* 1 or 2 */
-    uint32_t blas_chunks; /* bvh_levels = 2: number of bottom-level chunks, 0 = 64 (at least four triangles per chunk) */
+    uint32_t blas_chunks; /* bvh_levels = 2: number of bottom-level chunks, 0 = 64 (on average at least four triangles per chunk) */
 } rt_mesh_options;
 
 int rt_default_pt_params(rt_pt_params* p);
@@ -294,10 +294,12 @@ int rt_set_mesh_ex(rt_ctx* ctx, const float* verts, const float* albedo, const f
 /* Two-level meshes: the triangles of bottom-level chunk `chunk` (count, and their original indices into tri_ids[capacity]
  * when tri_ids != NULL), in the order rt_update_mesh_chunk expects their vertices. */
 int rt_mesh_chunk_info(rt_ctx* ctx, uint32_t chunk, uint32_t* count, uint32_t* tri_ids, uint32_t capacity);
-/* Two-level meshes: replace the vertices of one chunk's triangles (count * 9 floats, rt_mesh_chunk_info order; materials
- * and chunk membership stay) and rebuild that chunk's BVH, the top level and the flattened node array only.  The new
- * vertices must stay within the coordinate range of the mesh as first set (RT_ERR_INVALID otherwise: set the mesh again). */
-int rt_update_mesh_chunk(rt_ctx* ctx, uint32_t chunk, const float* verts);
+/* Two-level meshes: replace the vertices of one chunk's triangles (n_tris * 9 floats, rt_mesh_chunk_info order; materials
+ * and chunk membership stay) and rebuild that chunk's BVH, the top level and the flattened node array only.  n_tris must
+ * equal the chunk's triangle count (RT_ERR_INVALID otherwise: nothing is read).  The new vertices must stay within the
+ * coordinate range of the mesh as first set (RT_ERR_INVALID otherwise: set the mesh again).  Transactional: on any error
+ * other than RT_ERR_STATE the mesh is exactly as it was; RT_ERR_STATE means an upload failed and the mesh was dropped. */
+int rt_update_mesh_chunk(rt_ctx* ctx, uint32_t chunk, const float* verts, uint32_t n_tris);
 /* Synchronous path-traced frame of the current view (rt_resize) into host memory.
  * Every |pos| component must be <= 32 x max(1, largest |vertex coordinate| of the mesh): that is the range
  * over which the BVH's conservative box padding covers the fp32 rounding of the ray/box test (beyond it the

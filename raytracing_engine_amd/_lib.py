@@ -128,7 +128,7 @@ PROTOTYPES = {
     "rt_set_mesh": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32]),
     "rt_set_mesh_ex": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32, C.POINTER(MeshOptions)]),
     "rt_mesh_chunk_info": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, C.c_uint32]),
-    "rt_update_mesh_chunk": (C.c_int, [_vp, C.c_uint32, _fp]),
+    "rt_update_mesh_chunk": (C.c_int, [_vp, C.c_uint32, _fp, C.c_uint32]),
     "rt_render_pt": (C.c_int, [_vp, _fp, _fp, C.POINTER(PtParams), _fp]),
     "rt_render_pt_device": (C.c_int, [_vp, _fp, _fp, C.POINTER(PtParams), _vp, C.c_int]),
     "rt_get_pt_stats": (C.c_int, [_vp, C.POINTER(PtStats)]),

@@ -741,7 +741,8 @@ bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, ui
     for (uint32_t i = 0; i < n; i++) out->order[i] = i;
     std::vector<float> binary;
     // conservative padding: absorbs the rounding of the slab test and of Moeller-Trumbore's t
-    out->pad = out->pad_in >= 0.0f ? out->pad_in : 2e-5f * std::max(maxabs, 1.0f);
+    out->maxabs = std::max(maxabs, 1.0f);
+    out->pad = out->pad_in >= 0.0f ? out->pad_in : 2e-5f * out->maxabs;
     const uint32_t leaf_max = 1;  // the binary tree goes down to single triangles; the collapse keeps them as one-triangle leaves
     const int threads = out->max_threads > 0 ? std::min(out->max_threads, host_threads()) : host_threads();
     std::atomic<int> spare_threads{threads - 1};

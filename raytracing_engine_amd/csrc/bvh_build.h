@@ -35,6 +35,7 @@ struct BvhResult {
     uint32_t depth = 0;           // levels of 8-wide inner nodes (root = 1)
     uint32_t stack_need = 0;      // worst-case traversal stack occupancy (entries)
     float pad = 0.0f;             // conservative box padding that was applied
+    float maxabs = 1.0f;          // out: max(1, largest |vertex coordinate|): what the padding was chosen for (pad_in < 0: pad = 2e-5 * maxabs)
     double sah_area = 0.0;        // sum of child half-areas (quality metric)
 };
 
@@ -43,23 +44,28 @@ constexpr uint32_t kBvhMaxDepth = 30;  // depth cap of the binary tree before it
 // v0/e1/e2: n*3 floats each (edges already formed in fp32).  Returns false on invalid input.
 bool build_bvh(const float* v0, const float* e1, const float* e2, uint32_t n, uint32_t max_depth, BvhResult* out);
 
-// Two-level build ("TLAS over BLAS chunks", BASELINE.json configs[2]): the triangles are sorted along the Morton curve of
-// their centroids and cut into `chunks` equal runs, each run gets a BVH of its own (a bottom-level structure, build_bvh),
-// and a top-level BVH8 is built over the chunk boxes.  The result is flattened into ONE node array of the same format - a
+// Two-level build ("TLAS over BLAS chunks", BASELINE.json configs[2]): the triangle set is cut into `chunks` leaves of a
+// top-down binned-SAH split (the fullest leaf is split next, so chunk sizes stay within a small factor of each other and
+// chunk boxes do not overlap the way runs of a Morton order do), each chunk gets a BVH of its own (a bottom-level
+// structure, build_bvh), and a top-level BVH8 is built over the chunk boxes.  The result is flattened into ONE node array of the same format - a
 // top-level leaf simply becomes an inner child that is the chunk's root - so the traversal kernels do not know the
 // difference; what the split buys is that a chunk whose triangles moved is rebuilt alone (rebuild_chunk): 1/chunks of the
 // binned-SAH work plus a microscopic top level, then a re-flatten.
 struct TwoLevelBvh {
     std::vector<BvhResult> blas;            // per chunk, local node / triangle indices
-    std::vector<uint32_t> sorted;           // Morton order -> original triangle index; chunk c owns sorted[first[c] .. first[c + 1])
+    std::vector<uint32_t> sorted;           // chunk order -> original triangle index; chunk c owns sorted[first[c] .. first[c + 1]), ascending inside a chunk
     std::vector<uint32_t> first;            // chunks + 1 entries
     float pad = 0.0f;
+    float maxabs = 1.0f;                    // max(1, largest |vertex coordinate|) at build time: rebuild_chunk's coordinate range
     uint32_t tlas_nodes = 0, tlas_depth = 0;
-    double ms_blas = 0.0, ms_tlas = 0.0, ms_flatten = 0.0;  // wall time of the last (re)build's phases
+    double ms_cut = 0.0, ms_blas = 0.0, ms_tlas = 0.0, ms_flatten = 0.0;  // wall time of the last (re)build's phases
 };
 bool build_bvh_two_level(const float* v0, const float* e1, const float* e2, uint32_t n, uint32_t chunks, uint32_t max_depth, TwoLevelBvh* tl, BvhResult* out);
 // Rebuild bottom-level structure `chunk` from the current vertex data (v0/e1/e2 of the WHOLE mesh, original triangle order;
 // the chunk keeps its triangles), rebuild the top level over the new chunk boxes and flatten again into `out`.
-bool rebuild_chunk(const float* v0, const float* e1, const float* e2, uint32_t n, uint32_t chunk, uint32_t max_depth, TwoLevelBvh* tl, BvhResult* out);
+// Transactional: on failure (false, or an exception) `tl` is as it was.  On success `displaced` (may be NULL) receives the
+// chunk's previous structure, so a caller whose own later steps fail can put it back (std::swap(tl->blas[chunk], *displaced)).
+bool rebuild_chunk(const float* v0, const float* e1, const float* e2, uint32_t n, uint32_t chunk, uint32_t max_depth, TwoLevelBvh* tl, BvhResult* out,
+                   BvhResult* displaced = nullptr);
 
 }  // namespace rt

@@ -801,7 +801,8 @@ __global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : kPoolWaves) void pt_t
 // this costs about 100 vector instructions and one 48-byte vector load for 64 rays, against about 300
 // instructions and 64 x 5 sixteen-byte gathers in pt_trace.  Lanes whose octant differs from the packet
 // leader's (blocks that straddle a sign change of the direction) are walked in a further pass.
-constexpr int kPkStack = 40;  // >= kBvhMaxDepth + 2 groups: one pending sibling group per tree level
+constexpr int kPkStack = (int)kPacketStackEntries;  // one pending sibling group per tree level; render_pt_common sends trees whose stack_need exceeds it
+                                                   // (single-level: depth <= kBvhMaxDepth / 3 + 2; a flattened two-level tree adds its top level) to the per-lane kernel
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const PtFrame f, PtState st, unsigned long long* __restrict__ stats) {

@@ -67,6 +67,7 @@ void free_mesh(PtData& pt) {
     pt.host.reset();
     pt.cap_nodes = 0;
     pt.n_tris = pt.n_nodes = pt.n_lights = 0;
+    pt.stats = rt_pt_stats{};
 }
 
 template <class T>
@@ -193,7 +194,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         // padded by 2e-5 * M (M = largest |vertex coordinate|, at least 1): the invariant "results do not depend on
         // which boxes are visited"  holds for ray origins within about 40 M.  Bounce and shadow
         // rays start on the mesh; the camera is checked here.
-        const float reach = kCameraReach * (c->pt.bvh_pad / 2e-5f);
+        const float reach = kCameraReach * c->pt.bvh_maxabs;  // stored at build time (pad / 2e-5f does not round-trip in fp32)
         for (int a = 0; a < 3; a++)
             if (!(std::fabs(pos[a]) <= reach))
                 return c->fail(RT_ERR_INVALID, "camera position %g is outside +-%g (= %g x the mesh's largest |coordinate|): beyond the range the BVH box padding covers",
@@ -268,7 +269,9 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
 
         const size_t ctr_words = (size_t)rt::PT_CTR_STRIDE * (prm->bounces + 2);
         RT_HIP(c, hipMemsetAsync(pt.d_ctr, 0, ctr_words * sizeof(uint32_t), c->stream));
-        const bool packet = !prm->tune_no_packet;  // camera rays through the packet kernel, which makes its own rays: no generate stage, no queue 0
+        // camera rays through the packet kernel, which makes its own rays: no generate stage, no queue 0.  Its wave-uniform stack is a
+        // fixed LDS array: a tree that may need more (a deep two-level tree) takes the per-lane kernel, whose stack is sized from stack_need
+        const bool packet = !prm->tune_no_packet && pt.stack_need <= rt::kPacketStackEntries;
         if (!packet) {
             tm.begin(0);
             if (int rc = rt::launch_pt_generate(c, f, pt.st, pt.d_queue[0], pt.d_ctr)) return rc;
@@ -433,6 +436,7 @@ void pt_borrow_mesh(Ctx* lane, const Ctx* owner) {  // owner == nullptr: only fo
     d.bvh_depth = s.bvh_depth;
     d.bvh_build_ms = s.bvh_build_ms;
     d.bvh_pad = s.bvh_pad;
+    d.bvh_maxabs = s.bvh_maxabs;
     d.d_nodes = s.d_nodes;
     d.d_tris = s.d_tris;
     d.d_albedo = s.d_albedo;
@@ -502,6 +506,7 @@ void publish_bvh_stats(PtData& pt, const rt::BvhResult& bvh) {
     pt.bvh_depth = bvh.depth;
     pt.stack_need = bvh.stack_need;
     pt.bvh_pad = bvh.pad;
+    pt.bvh_maxabs = bvh.maxabs;
     pt.stats.n_nodes = bvh.n_nodes;
     pt.stats.bvh_depth = bvh.depth;
     pt.stats.stack_need = bvh.stack_need;
@@ -595,13 +600,14 @@ int set_mesh_impl(Ctx* c, const float* verts, const float* albedo, const float* 
     return RT_OK;
 }
 
-int update_chunk_impl(Ctx* c, uint32_t chunk, const float* verts) {
+int update_chunk_impl(Ctx* c, uint32_t chunk, const float* verts, uint32_t n_tris) {
     PtData& pt = c->pt;
     if (!pt.host || pt.borrowed_mesh) return c->fail(RT_ERR_STATE, "rt_update_mesh_chunk needs a two-level mesh (rt_set_mesh_ex with bvh_levels = 2) owned by this context");
     rt::MeshHost& h = *pt.host;
     if (chunk >= h.tl.blas.size()) return c->fail(RT_ERR_INVALID, "chunk %u of %zu", chunk, h.tl.blas.size());
     if (!verts) return c->fail(RT_ERR_INVALID, "verts is NULL");
     const uint32_t first = h.tl.first[chunk], count = h.tl.first[chunk + 1] - first;
+    if (n_tris != count) return c->fail(RT_ERR_INVALID, "chunk %u holds %u triangles, verts holds %u (rt_mesh_chunk_info)", chunk, count, n_tris);
     for (size_t i = 0; i < (size_t)count * 9; i++)
         if (!std::isfinite(verts[i])) return c->fail(RT_ERR_INVALID, "vertex data is not finite at float %zu", i);
     if (int rc = bind(c)) return rc;
@@ -610,65 +616,98 @@ int update_chunk_impl(Ctx* c, uint32_t chunk, const float* verts) {
     rt::frames_drop_mesh(c);  // lanes re-borrow the mesh on their next submit
     c->state_version++;
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<float> old((size_t)count * 9);  // to restore the host copy if the rebuild is refused
+    // Transactional: the host copy and the chunk's bottom-level structure change first and are put back if anything up to
+    // the device allocation fails; the device arrays are written only after everything host-side (and the node array's
+    // regrow) has succeeded.  An upload that fails half-way leaves the device arrays undefined: the mesh is dropped then.
+    std::vector<float> old((size_t)count * 9);
+    auto swap_in = [&](const float* src, bool edges_formed) {
+        for (uint32_t i = 0; i < count; i++) {
+            const size_t t = h.tl.sorted[first + i];
+            for (int a = 0; a < 3; a++) {
+                h.v0[3 * t + a] = src[9 * (size_t)i + a];
+                h.e1[3 * t + a] = edges_formed ? src[9 * (size_t)i + 3 + a] : src[9 * (size_t)i + 3 + a] - src[9 * (size_t)i + a];
+                h.e2[3 * t + a] = edges_formed ? src[9 * (size_t)i + 6 + a] : src[9 * (size_t)i + 6 + a] - src[9 * (size_t)i + a];
+            }
+        }
+    };
     for (uint32_t i = 0; i < count; i++) {
         const size_t t = h.tl.sorted[first + i];
         for (int a = 0; a < 3; a++) {
             old[9 * (size_t)i + a] = h.v0[3 * t + a];
             old[9 * (size_t)i + 3 + a] = h.e1[3 * t + a];
             old[9 * (size_t)i + 6 + a] = h.e2[3 * t + a];
-            h.v0[3 * t + a] = verts[9 * (size_t)i + a];
-            h.e1[3 * t + a] = verts[9 * (size_t)i + 3 + a] - verts[9 * (size_t)i + a];
-            h.e2[3 * t + a] = verts[9 * (size_t)i + 6 + a] - verts[9 * (size_t)i + a];
         }
     }
-    rt::BvhResult bvh;
+    swap_in(verts, false);
+    rt::BvhResult bvh, displaced;
     const uint32_t n = pt.n_tris;
-    if (!rt::rebuild_chunk(h.v0.data(), h.e1.data(), h.e2.data(), n, chunk, rt::kBvhMaxDepth, &h.tl, &bvh)) {
-        for (uint32_t i = 0; i < count; i++) {
-            const size_t t = h.tl.sorted[first + i];
-            for (int a = 0; a < 3; a++) {
-                h.v0[3 * t + a] = old[9 * (size_t)i + a];
-                h.e1[3 * t + a] = old[9 * (size_t)i + 3 + a];
-                h.e2[3 * t + a] = old[9 * (size_t)i + 6 + a];
-            }
-        }
+    bool built = false;
+    try {
+        built = rt::rebuild_chunk(h.v0.data(), h.e1.data(), h.e2.data(), n, chunk, rt::kBvhMaxDepth, &h.tl, &bvh, &displaced);
+    } catch (...) {
+        swap_in(old.data(), true);
+        throw;  // guarded() turns it into a status; the mesh is as it was
+    }
+    if (!built) {
+        swap_in(old.data(), true);
         return c->fail(RT_ERR_INVALID, "chunk rebuild refused: the moved vertices leave the coordinate range the mesh's box padding was chosen for (call rt_set_mesh_ex again)");
     }
+    auto roll_back = [&]() {
+        std::swap(h.tl.blas[chunk], displaced);
+        swap_in(old.data(), true);
+    };
     pt.bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    float4* new_nodes = nullptr;
+    size_t new_cap = pt.cap_nodes;
     if (bvh.n_nodes > pt.cap_nodes) {
-        dfree(pt.d_nodes);
-        pt.cap_nodes = (size_t)bvh.n_nodes + bvh.n_nodes / 8 + 1024;
-        if (!dalloc(pt.d_nodes, pt.cap_nodes * 5)) {
-            free_mesh(pt);
-            return c->fail(RT_ERR_OOM, "node array of %u nodes", bvh.n_nodes);
+        new_cap = (size_t)bvh.n_nodes + bvh.n_nodes / 8 + 1024;
+        if (!dalloc(new_nodes, new_cap * 5)) {
+            roll_back();
+            return c->fail(RT_ERR_OOM, "node array of %u nodes (the mesh is unchanged)", bvh.n_nodes);
         }
     }
     // the chunk's triangles keep their range of the leaf order (chunks are laid out in chunk order); inside it the order is new
     size_t li0 = 0;
     for (uint32_t b = 0; b < chunk; b++) li0 += h.tl.blas[b].order.size();
     const size_t li1 = li0 + count;
-    std::vector<float> tris(12 * (size_t)count), alb(4 * (size_t)count), emi(4 * (size_t)count);
-    pack_leaf_range(bvh, h.v0.data(), h.e1.data(), h.e2.data(), h.albedo.data(), h.emission.data(), li0, li1, tris.data(), alb.data(), emi.data());
-    RT_HIP(c, hipMemcpy(pt.d_nodes, bvh.nodes.data(), (size_t)bvh.n_nodes * 80, hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(pt.d_tris + li0 * 3, tris.data(), (size_t)count * 48, hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(pt.d_albedo + li0, alb.data(), (size_t)count * 16, hipMemcpyHostToDevice));
-    RT_HIP(c, hipMemcpy(pt.d_emission + li0, emi.data(), (size_t)count * 16, hipMemcpyHostToDevice));
-    if (!h.light_ids.empty()) {  // lights are listed by leaf position, in ascending original index
-        std::vector<uint32_t> leaf_of(h.light_ids.size(), 0u);
-        bool moved = false;
-        for (size_t li = li0; li < li1; li++) {
-            const auto it = std::lower_bound(h.light_ids.begin(), h.light_ids.end(), bvh.order[li]);
-            if (it != h.light_ids.end() && *it == bvh.order[li]) moved = true;
+    std::vector<float> tris, alb, emi;
+    std::vector<uint32_t> leaf_of;
+    try {
+        tris.resize(12 * (size_t)count);
+        alb.resize(4 * (size_t)count);
+        emi.resize(4 * (size_t)count);
+        pack_leaf_range(bvh, h.v0.data(), h.e1.data(), h.e2.data(), h.albedo.data(), h.emission.data(), li0, li1, tris.data(), alb.data(), emi.data());
+        if (!h.light_ids.empty()) {  // lights are listed by leaf position, in ascending original index
+            bool moved = false;
+            for (size_t li = li0; li < li1 && !moved; li++) moved = std::binary_search(h.light_ids.begin(), h.light_ids.end(), bvh.order[li]);
+            if (moved) {
+                std::vector<uint32_t> leaf_pos(n);
+                for (size_t li = 0; li < n; li++) leaf_pos[bvh.order[li]] = (uint32_t)li;
+                leaf_of.resize(h.light_ids.size());
+                for (size_t k = 0; k < h.light_ids.size(); k++) leaf_of[k] = leaf_pos[h.light_ids[k]];
+            }
         }
-        if (moved) {
-            std::vector<uint32_t> leaf_pos(n);
-            for (size_t li = 0; li < n; li++) leaf_pos[bvh.order[li]] = (uint32_t)li;
-            for (size_t k = 0; k < h.light_ids.size(); k++) leaf_of[k] = leaf_pos[h.light_ids[k]];
-            RT_HIP(c, hipMemcpy(pt.d_lights, leaf_of.data(), leaf_of.size() * 4, hipMemcpyHostToDevice));
-        }
+    } catch (...) {
+        dfree(new_nodes);
+        roll_back();
+        throw;
     }
-    RT_HIP(c, hipDeviceSynchronize());  // null-stream uploads before anything on the context's non-blocking streams
+    // commit to the device
+    if (new_nodes) {
+        dfree(pt.d_nodes);
+        pt.d_nodes = new_nodes;
+        pt.cap_nodes = new_cap;
+    }
+    hipError_t e = hipMemcpy(pt.d_nodes, bvh.nodes.data(), (size_t)bvh.n_nodes * 80, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pt.d_tris + li0 * 3, tris.data(), (size_t)count * 48, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pt.d_albedo + li0, alb.data(), (size_t)count * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pt.d_emission + li0, emi.data(), (size_t)count * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !leaf_of.empty()) e = hipMemcpy(pt.d_lights, leaf_of.data(), leaf_of.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();  // null-stream uploads before anything on the context's non-blocking streams
+    if (e != hipSuccess) {
+        free_mesh(pt);  // host tree and device arrays may disagree: no frame may be traced against them
+        return c->fail(RT_ERR_STATE, "chunk upload failed (%s): the mesh has been dropped, call rt_set_mesh_ex again", hipGetErrorString(e));
+    }
     pt.stats.ms_build_blas = (float)h.tl.ms_blas;
     pt.stats.ms_build_tlas = (float)h.tl.ms_tlas;
     pt.stats.ms_build_flatten = (float)h.tl.ms_flatten;
@@ -677,22 +716,22 @@ int update_chunk_impl(Ctx* c, uint32_t chunk, const float* verts) {
 }
 
 template <class F>
-int guarded(Ctx* c, const char* what, F&& f) {
+int guarded(Ctx* c, const char* what, F&& f, bool drop_mesh = true) {  // drop_mesh = false: the callee has put the mesh back before it threw
     // the builder allocates host vectors sized by n_tris and starts std::threads: nothing may leave an entry point
     // as a C++ exception (include/rt_abi.h: never throws or aborts across the boundary)
     try {
         return f();
     } catch (const std::bad_alloc&) {
-        free_mesh(c->pt);
+        if (drop_mesh) free_mesh(c->pt);
         return c->fail(RT_ERR_OOM, "%s: out of host memory", what);
     } catch (const std::system_error& e) {
-        free_mesh(c->pt);
+        if (drop_mesh) free_mesh(c->pt);
         return c->fail(RT_ERR_STATE, "%s: %s", what, e.what());
     } catch (const std::exception& e) {
-        free_mesh(c->pt);
+        if (drop_mesh) free_mesh(c->pt);
         return c->fail(RT_ERR_INVALID, "%s: %s", what, e.what());
     } catch (...) {
-        free_mesh(c->pt);
+        if (drop_mesh) free_mesh(c->pt);
         return c->fail(RT_ERR_INVALID, "%s failed", what);
     }
 }
@@ -725,10 +764,10 @@ int rt_mesh_chunk_info(rt_ctx* ctx, uint32_t chunk, uint32_t* count, uint32_t* t
     return RT_OK;
 }
 
-int rt_update_mesh_chunk(rt_ctx* ctx, uint32_t chunk, const float* verts) {
+int rt_update_mesh_chunk(rt_ctx* ctx, uint32_t chunk, const float* verts, uint32_t n_tris) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c) return RT_ERR_INVALID;
-    return guarded(c, "chunk rebuild", [&] { return update_chunk_impl(c, chunk, verts); });
+    return guarded(c, "chunk rebuild", [&] { return update_chunk_impl(c, chunk, verts, n_tris); }, false);
 }
 
 int rt_render_pt(rt_ctx* ctx, const float rot[4], const float pos[3], const rt_pt_params* params, float* rgb_out) {

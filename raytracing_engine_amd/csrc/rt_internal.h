@@ -139,6 +139,7 @@ struct PtScene {
     uint32_t n_tris;
 };
 
+constexpr uint32_t kPacketStackEntries = 40;  // pt_trace_packet's LDS stack of node groups (path_b.hip)
 enum { TRI_MODE_INLINE = 1, TRI_MODE_POOL = 2, TRI_MODE_DEFER = 3 };  // rt_pt_params.tune_tri_mode, byte 0 (path_b.hip: TRI_INLINE, TRI_POOL)
 
 struct StackCfg {  // per-lane traversal stack of 8-byte entries: lds_cap in LDS, then spill_cap in global memory
@@ -185,7 +186,7 @@ struct PtData {  // device residency of one mesh + the wavefront buffers
     size_t cap_nodes = 0;            // nodes d_nodes has room for
     bool borrowed_mesh = false;  // the mesh arrays belong to another context (frame-slot lanes share their parent's mesh)
     uint32_t n_tris = 0, n_nodes = 0, n_lights = 0, bvh_depth = 0;
-    float bvh_build_ms = 0.0f, bvh_pad = 0.0f;
+    float bvh_build_ms = 0.0f, bvh_pad = 0.0f, bvh_maxabs = 1.0f;  // bvh_maxabs = max(1, largest |vertex coordinate|): what the padding covers
     float4* d_nodes = nullptr;
     float4* d_tris = nullptr;
     float4* d_albedo = nullptr;

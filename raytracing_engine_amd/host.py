@@ -316,7 +316,7 @@ class Renderer:
     def update_mesh_chunk(self, chunk, verts):
         """New vertices (count x 9, mesh_chunk order) for one chunk of a two-level mesh: only that chunk is rebuilt."""
         verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 9)
-        self._check(self._lib.rt_update_mesh_chunk(self._ctx, chunk, _fptr(verts)))
+        self._check(self._lib.rt_update_mesh_chunk(self._ctx, chunk, _fptr(verts), len(verts)))  # the C side checks the count against the chunk
 
     def pt_params(self, spp=4, bounces=1, seed=1, sky=(0.0, 0.0, 0.0), ray_eps=1e-3, count_traversal=False, max_paths=0, tune_refill_min=0,
                   tune_blocks_per_cu=0, tune_lds_stack=0, tune_no_overlap=0, tune_no_packet=0, tune_sort_rays=0, tune_tri_mode=0):

@@ -44,6 +44,17 @@ def test_builder_threads_are_race_free_and_deterministic(checker_tsan):
     assert one.returncode == 0 and one.stdout == many.stdout, one.stdout + one.stderr
 
 
+def test_two_level_cut_is_race_free_and_deterministic(checker_tsan):
+    """The SAH cut of the two-level build splits leaves side by side and bins big leaves on several threads: ThreadSanitizer
+    must stay silent, and one CPU must produce the very same flattened tree (hash of nodes + leaf order) as all of them."""
+    many = subprocess.run([checker_tsan, "150000", "11", "0.2", "64"], capture_output=True, text=True)
+    assert many.returncode == 0 and many.stdout.startswith("OK") and "ThreadSanitizer" not in many.stderr, many.stdout + many.stderr
+    one = subprocess.run(["taskset", "-c", "0", checker_tsan, "150000", "11", "0.2", "64"], capture_output=True, text=True)
+    assert one.returncode == 0 and one.stdout == many.stdout, one.stdout + one.stderr
+    odd = subprocess.run([checker_tsan, "150000", "11", "0.2", "37"], capture_output=True, text=True)  # not a power of two: the fullest leaves split first
+    assert odd.returncode == 0 and odd.stdout.startswith("OK") and "ThreadSanitizer" not in odd.stderr, odd.stdout + odd.stderr
+
+
 @pytest.fixture(scope="module")
 def checker_limited(tmp_path_factory):
     """bvh_check with tests/native/thread_limit.cpp: pthread_create fails with EAGAIN after

@@ -386,10 +386,13 @@ def test_two_level_bvh_frames_counts_and_chunk_rebuild(renderer, walker, tmp_pat
     assert np.array_equal(rec["nodes"], counts[:, 0]) and np.array_equal(rec["tris"], counts[:, 1])
     # move the triangles of one chunk (the light's chunk too, so the light list has to follow) and rebuild only it
     light_chunk = next(c for c in range(64) if (len(v) - 1) in renderer.mesh_chunk(c))
+    sizes = [len(renderer.mesh_chunk(c)) for c in range(64)]  # leaves of the SAH cut: not equal, but the fullest leaf is always split next
+    assert sum(sizes) == len(v) and min(sizes) >= 1 and max(sizes) <= 4 * (len(v) // 64)
+    assert len(np.unique(np.concatenate([renderer.mesh_chunk(c) for c in range(64)]))) == len(v)
     v2 = v.copy()
     for chunk in (5, light_chunk):
         ids = renderer.mesh_chunk(chunk)
-        assert len(ids) in (len(v) // 64, len(v) // 64 + 1) and len(np.unique(ids)) == len(ids)
+        assert len(np.unique(ids)) == len(ids)
         v2[ids] += np.tile(np.array([0.4, -0.3, 0.2], np.float32), 3)
         renderer.update_mesh_chunk(chunk, v2[ids])
     st = renderer.pt_stats()
@@ -409,6 +412,10 @@ def test_two_level_bvh_frames_counts_and_chunk_rebuild(renderer, walker, tmp_pat
     with pytest.raises(R.RtError) as ei:
         renderer.update_mesh_chunk(0, v2[ids] * 100.0)
     assert ei.value.code == -1
+    for wrong in (v2[ids][:-1], np.concatenate([v2[ids], v2[ids][:1]])):  # a vertex array that is not the chunk's size is refused, not read
+        with pytest.raises(R.RtError) as ei:
+            renderer.update_mesh_chunk(0, wrong)
+        assert ei.value.code == -1 and "holds" in str(ei.value)
     assert np.array_equal(renderer.render_pt(**kw), ref2)
     renderer.set_mesh(v, a, e)
     with pytest.raises(R.RtError) as ei:
@@ -440,6 +447,32 @@ def test_packet_kernel_camera_poses(renderer, yaw, pitch, pos, spp, w, h):
     renderer.render_pt(rot, pos, spp=spp, bounces=1, seed=9, sky=(0.3, 0.3, 0.4), count_traversal=True)
     ct = renderer.pt_stats()
     assert ct["packets"] == -(-(-(-w // 64) * -(-h // 64) * 4096 * spp) // 64) and ct["packet_nodes_fetched"] >= ct["packets"]
+
+
+def test_chunk_update_accepts_the_mesh_it_was_built_from(renderer):
+    """rt_update_mesh_chunk checks the new vertices against the coordinate range the box padding was chosen for.  That range is
+    stored at build time: reconstructing it as pad / 2e-5 loses an ulp for about 8 % of the ranges (100.0 among them) and then
+    refuses the very chunk that holds the extreme vertex, even unchanged."""
+    v, a, e = scenes.soup_scene(4000, seed=21, edge=0.5)
+    v = v.copy()
+    v[123, 0] = 100.0  # largest |coordinate| of the mesh: exactly 100.0
+    assert np.abs(v).max() == np.float32(100.0)
+    assert np.float32(np.float32(2e-5) * np.float32(100.0)) / np.float32(2e-5) < np.float32(100.0)  # the round trip this test is about
+    kw = dict(spp=1, bounces=1, seed=4, sky=(0.2, 0.2, 0.25))
+    renderer.resize(96, 64)
+    renderer.set_mesh(v, a, e, bvh_levels=2, blas_chunks=16)
+    before = renderer.render_pt(**kw)
+    for chunk in range(16):
+        ids = renderer.mesh_chunk(chunk)
+        renderer.update_mesh_chunk(chunk, v[ids])  # unchanged vertices: every chunk, the extreme vertex's too, must be accepted
+    assert np.array_equal(renderer.render_pt(**kw), before)
+    ref, _ = O.TriScene(v, a, e).render(96, 64, **kw)
+    assert np.array_equal(before, ref)
+    # the camera reach (32 x the stored range) is exact as well
+    assert np.array_equal(renderer.render_pt(pos=(0, -3200.0, 0), **kw), O.TriScene(v, a, e).render(96, 64, pos=(0, -3200.0, 0), **kw)[0])
+    with pytest.raises(R.RtError):
+        renderer.render_pt(pos=(0, -3200.5, 0), **kw)
+    renderer.resize(64, 64)
 
 
 @pytest.mark.parametrize("n_tris", [1, 3, 38, 700])
