@@ -130,8 +130,8 @@ def path_b(name, n_tris, edge, w, h, spp, bounces, cpu_rows, cpu_spp, levels=1, 
 
 path_a("1: 8 spheres + 1 light, 256x256, 1 spp (CPU only)", 256, 256, 1, gpu=False)
 path_a("2: same scene, 1920x1080, 4 spp", 1920, 1080, 4)
-path_b("3: 100 k triangles, single-level BVH8, 1920x1080, 4 spp, 1 bounce", 100_000, 0.25, 1920, 1080, 4, 1, (0, 1080), 1)
-path_b("3 (two-level BVH: top level over 64 chunks): as 3", 100_000, 0.25, 1920, 1080, 4, 1, (0, 1080), 1, levels=2, cpu=False)
+path_b("3: 100 k triangles, 2-level BVH (top level over 64 SAH-cut chunks), 1920x1080, 4 spp, 1 bounce", 100_000, 0.25, 1920, 1080, 4, 1, (0, 1080), 1, levels=2)
+path_b("3 (single-level BVH8, for comparison): as 3", 100_000, 0.25, 1920, 1080, 4, 1, (0, 1080), 1, cpu=False)
 path_b("4: 1 M triangles, 1920x1080, 8 spp, 1 bounce (1 GPU of 8)", 1_000_000, 0.08, 1920, 1080, 8, 1, (0, 1080), 1)
 path_b("5: 1 M triangles, 3840x2160, 64 spp, 8 bounces (1 GPU of 8)", 1_000_000, 0.08, 3840, 2160, 64, 8, (1000, 1128), 1)
 
