@@ -12,6 +12,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liboracle.so")
+# ORACLE_SO: another build of the same sources, e.g. `make -C oracle asan` -> _build/liboracle_asan.so (tests/test_oracle_sanitized.py)
+_SO_OVERRIDE = os.environ.get("ORACLE_SO")
 
 
 def build(force=False):
@@ -63,8 +65,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_SO)
+        if not _SO_OVERRIDE:
+            build()
+        L = C.CDLL(_SO_OVERRIDE or _SO)
         fp = C.POINTER(C.c_float)
         L.ora_default_config.argtypes = [C.POINTER(Config)]
         L.ora_default_scene.argtypes = [C.POINTER(Scene)]

@@ -43,6 +43,28 @@ def counts(st):
     return {k: st[k] for k in ("camera_rays", "bounce_rays", "shadow_rays")}
 
 
+def test_config2_tri100k_two_level_1080p_4spp(renderer, pinned):
+    """configs[2] AS NAMED: 100 k random triangles with the 2-level BVH (top level over 64 bottom-level chunks), 1920x1080,
+    4 spp: whole-frame ray counts against the oracle's (pinned), three bands of the frame bit for bit, and the frame equal to
+    the single-level tree's.  (Runs before the module's 1 M-triangle fixture puts its mesh on the device.)"""
+    mesh = scenes.soup_scene(100_000, seed=1, edge=0.25)
+    renderer.set_partition(0, 1)
+    renderer.resize(1920, 1080)
+    renderer.set_mesh(*mesh, bvh_levels=2, blas_chunks=64)
+    st = renderer.pt_stats()
+    assert st["bvh_levels"] == 2 and st["blas_chunks"] == 64 and st["tlas_nodes"] >= 9
+    rgb = renderer.render_pt(spp=4, bounces=1, seed=1, sky=SKY)
+    st = renderer.pt_stats()
+    assert st["stack_overflow"] == 0 and np.isfinite(rgb).all()
+    assert counts(st) == {k: pinned["tri100k_1080p_4spp"][k] for k in counts(st)}
+    sc = O.TriScene(*mesh)
+    for rows in [(0, 8), (536, 552), (1072, 1080)]:
+        band, _ = sc.render(1920, 1080, spp=4, bounces=1, seed=1, sky=SKY, rows=rows)
+        assert np.array_equal(rgb[rows[0]:rows[1]], band), rows
+    renderer.set_mesh(*mesh)
+    assert np.array_equal(renderer.render_pt(spp=4, bounces=1, seed=1, sky=SKY), rgb)
+
+
 def test_metric_workload_tri1m_1080p_4spp(renderer, tri1m, pinned):
     """BASELINE.json metric config = bench.py's default workload."""
     _, sc = tri1m

@@ -274,6 +274,29 @@ def test_spp4_stratified(renderer):
     assert renderer.stats()["primary_rays"] == w * h * 4
 
 
+def test_config1_spheres8_1080p_4spp(renderer):
+    """BASELINE.json configs[1] AS NAMED: the 8-sphere room, 1920x1080, 4 spp (= 2 x 2 stratified sub-pixel centres, each one
+    full frame, averaged in sample order: DESIGN.md section 5) against four oracle frames; ray counts equal."""
+    scene = R.cornell_scene()
+    w, h, n = 1920, 1080, 2
+    renderer.set_scene(scene)
+    renderer.resize(w, h)
+    rgb = renderer.render(spp=4)
+    st = renderer.stats()
+    acc, shadow = None, 0
+    for s in range(4):
+        i, j = s % n, s // n
+        jit = (((np.float32(2 * i + 1) / np.float32(n)) - np.float32(1)) / np.float32(w),
+               ((np.float32(2 * j + 1) / np.float32(n)) - np.float32(1)) / np.float32(h))
+        o = O.render_a(oracle_scene(scene), w, h, jitter=jit, want_levels=False)
+        acc = o["rgb"] if acc is None else acc + o["rgb"]
+        shadow += o["counters"]["shadow_rays"]
+    err = np.abs(rgb - acc / np.float32(4)).max()
+    assert err <= RGB_TOL, err
+    assert st["primary_rays"] == w * h * 4 and st["shadow_rays"] == shadow
+    renderer.resize(64, 64)
+
+
 def test_deterministic_and_rgba8(renderer):
     scene = R.cornell_scene()
     renderer.set_scene(scene)
