@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="tri1m_1080p_4spp", help="tri1m_1080p_4spp (metric config) | spheres8_1080p_4spp")
+    ap.add_argument("--workload", default="tri1m_1080p_4spp",
+                    help="tri1m_1080p_4spp (metric config) | spheres8_1080p_4spp (configs[1]) | terrain1m_1080p_4spp, tri16m_1080p_4spp (context)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (the timed frame checked against the oracle after the timed region)")
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)  # CPU test of the launcher + N>1 control flow (gloo, no GPU, no kernels)
@@ -66,13 +67,9 @@ def host_threads():
     return n
 
 
-def measure_traffic(workload, kernel_substr):
-    """HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC counters, as
-    /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE passes
-    (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2), with --kernel-trace only; on gfx950 FETCH_SIZE
-    tallies 128-byte requests as 64 bytes, so the read side is doubled (calibrated for wide streaming
-    reads; for these 16-byte gathers it is an upper bound of the correction).  Each pass profiles a
-    child process that runs two steps of the same workload.  Returns None when rocprofv3 is unusable."""
+def pmc_pass(workload, kernel_substr, counters):
+    """One rocprofv3 PMC pass (--kernel-trace + --pmc only, the program directly after "--") over a child process that runs
+    two steps of the workload: {counter: average value per launch of the kernel}.  None when rocprofv3 is unusable."""
     import csv
     import glob
     import shutil
@@ -81,28 +78,73 @@ def measure_traffic(workload, kernel_substr):
 
     if shutil.which("rocprofv3") is None:
         return None
-    kb = {}
+    d = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
-            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-                   sys.executable, os.path.abspath(__file__), "--traffic-child", "--workload", workload]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=600, check=True,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            vals = []
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
-                        vals.append(float(row["Counter_Value"]))
-            shutil.rmtree(d, ignore_errors=True)
-            if not vals:
-                return None
-            kb[counter] = sum(vals) / len(vals)
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.abspath(__file__), "--traffic-child", "--workload", workload]
+        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=900, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        vals = {c: [] for c in counters}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] in vals and kernel_substr in row["Kernel_Name"]:
+                    vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        if not all(vals.values()):
+            return None
+        return {c: sum(v) / len(v) for c, v in vals.items()}
     except (OSError, subprocess.SubprocessError, KeyError, ValueError):
         return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def measure_traffic(workload, kernel_substr):
+    """Fabric-side bytes per launch of the dominant kernel from rocprofv3 PMC counters, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE passes
+    (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2), with --kernel-trace only; on gfx950 FETCH_SIZE
+    tallies 128-byte requests as 64 bytes, so the read side is doubled (calibrated for wide streaming
+    reads; for these 16-byte gathers it is an upper bound of the correction).  These are L2 MISSES: requests
+    the L2 sent to the fabric, whether the Infinity Cache (256 MiB) or HBM answered them - an upper bound of
+    the HBM traffic, close to it only when the working set exceeds the Infinity Cache.  Returns None when
+    rocprofv3 is unusable."""
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        got = pmc_pass(workload, kernel_substr, [counter])
+        if got is None:
+            return None
+        kb[counter] = got[counter]
     return {"bytes_per_launch": kb["FETCH_SIZE"] * 1024.0 * 2.0 + kb["WRITE_SIZE"] * 1024.0,
             "fetch_size_kb_raw": round(kb["FETCH_SIZE"], 1), "write_size_kb_raw": round(kb["WRITE_SIZE"], 1),
             "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as read"}
+
+
+# Issue cost of one wave64 vector instruction on one SIMD, measured by tools/valu_rate_bench.hip at 8 waves per SIMD
+# (profiles/r02_valu_issue_rates.txt): v_fma / v_mul / v_add / v_mov_b32 2.65-2.87 cycles, every other class the traversal
+# kernels use (v_cvt_f32_ubyteN, v_max3 / v_min3, v_cmp, v_cndmask, shifts, bit-field and logic ops, integer multiplies) 4.3-4.8.
+VALU_FAST_CYCLES, VALU_OTHER_CYCLES = 2.75, 4.7
+# Share of the fast class among the vector instructions of the per-lane traversal kernels' code (static count over the ISA of
+# pt_trace_fused: 310 of 1180; the node step itself is 96 fma / cvt pairs in 192): tools/valu_mix.py prints it from the built library.
+VALU_FAST_SHARE = 0.26
+N_SIMDS = 256 * 4
+
+
+def measure_valu_issue(workload, kernel_substr):
+    """The vector-ALU side of the dominant kernel from one PMC pass: wave-level vector instructions per launch, lanes active per
+    instruction, the SQ's own busy figure, and the issue-slot fraction = instructions x measured issue cycles / (SIMDs x kernel cycles)."""
+    got = pmc_pass(workload, kernel_substr, ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])
+    if got is None:
+        return None
+    insts = got["SQ_INSTS_VALU"]
+    cycles = got["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+    avg = VALU_FAST_SHARE * VALU_FAST_CYCLES + (1.0 - VALU_FAST_SHARE) * VALU_OTHER_CYCLES
+    return {"bound": "valu_issue", "insts_per_launch": insts, "lanes_per_instruction": round(got["SQ_THREAD_CYCLES_VALU"] / max(insts, 1.0), 1),
+            "kernel_cycles": round(cycles), "issue_cycles_per_instruction": round(avg, 2),
+            "frac": round(insts * avg / (N_SIMDS * max(cycles, 1.0)), 3),
+            "sq_active_inst_valu_frac": round(got["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * max(cycles, 1.0)), 3),
+            "definition": "SQ_INSTS_VALU x issue cycles per instruction (0.26 x 2.75 + 0.74 x 4.7, tools/valu_rate_bench.hip at 8 waves per SIMD) / "
+                          "(1024 SIMDs x GRBM_GUI_ACTIVE / 8); about 1 = every issue slot taken (the isolated-stream costs overstate a mixed "
+                          "stream by a few per cent); lanes_per_instruction = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU of the same pass; "
+                          "sq_active_inst_valu_frac = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / the same denominator"}
 
 
 # Gather ceilings of the cache hierarchy for the BVH node access pattern (every lane reads one random 80-byte
@@ -112,8 +154,9 @@ GATHER_CEILING_IC_TBS = 4.4    # 16-20 MiB table, served from the Infinity Cache
 
 
 def finish_roofline(rl, traffic):
-    """`achieved` / `frac` of the HBM roofline from the HBM-side bytes the PMC counters saw per launch of the
-    dominant kernel (a bound: <= 1 by construction) when they could be collected; the algorithmic figure
+    """`achieved` / `frac` of the HBM roofline from the L2-miss (fabric-side) bytes the PMC counters saw per launch of the
+    dominant kernel - Infinity-Cache hits included, so an UPPER bound of the HBM traffic and of the fraction - when they
+    could be collected; the algorithmic figure
     (every fetch charged as if it came from HBM) stays beside it under `algorithmic`, where
     a cache-resident scene makes it exceed the HBM peak - that ratio is node visits per second, not a
     roofline fraction, and is not called one."""
@@ -127,7 +170,9 @@ def finish_roofline(rl, traffic):
         rl.update(achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4), hbm_counter_frac=round(ach / HBM_PEAK_GBS, 4),
                   traffic=traffic["bytes_per_launch"], traffic_detail=traffic,
                   traffic_over_algorithmic=round(traffic["bytes_per_launch"] / alg, 3),
-                  achieved_definition="HBM-side bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes) / avg_kernel_ms")
+                  achieved_definition="L2-miss (fabric-side) bytes per launch incl. Infinity-Cache hits, from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, "
+                                      "separate passes) / avg_kernel_ms: an upper bound of the HBM traffic; equal to it only when the working set "
+                                      "exceeds the 256 MiB Infinity Cache (workload tri16m_1080p_4spp)")
     elif alg_gbs <= HBM_PEAK_GBS:  # counters unavailable: the algorithmic figure is still a valid lower bound on the fraction
         rl.update(achieved=round(alg_gbs, 1), frac=round(alg_gbs / HBM_PEAK_GBS, 4), hbm_counter_frac=None, traffic=None,
                   achieved_definition="algorithmic bytes per launch / avg_kernel_ms (PMC traffic not collected)")
@@ -150,8 +195,7 @@ def launch_ranks(n):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n))  # HSA_ENABLE_IPC_MODE_LEGACY: set by main()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=None if r == 0 else sys.stderr) for r in range(n)]
     rc, alive = 0, set(range(n))
@@ -414,6 +458,14 @@ class TriWorkload:
                 "width": self.width, "height": self.height, "spp": self.spp, "bounces": self.bounces, "tile": 64,
                 "bvh_build_ms_host": round(st["bvh_build_ms"], 1)}
 
+    def set_share(self, world, n_lanes):
+        """A rank's share of the frame and the frame lanes it is rendered on: with a 1/8 share on several lanes the persistent
+        traversal launches of the lanes fill the machine TOGETHER, and two workgroups per CU per launch instead of the four
+        the context would pick for a lone frame of that size measured best (tools/partition_scaling.py --tune
+        tune_blocks_per_cu=2: 1.43 against 1.48 ms per frame with three lanes; profiles/r03_partition_scaling.txt)."""
+        if world >= 8 and n_lanes >= 2 and "tune_blocks_per_cu" not in tune_from_env():
+            self.params.tune_blocks_per_cu = 2
+
     def step(self, out_ptr, tile_major):
         self.r.render_pt_device(self.rot, self.pos, self.params, out_ptr, tile_major)
 
@@ -513,8 +565,10 @@ class TriWorkload:
                            "counted_by": "the kernels' COUNT instantiations on their BVH8; the per-lane step functions are cross-checked per ray against a host "
                                          "walk of the same tree (tests/test_gpu_path_b.py::test_traversal_counts_match_the_host_walk_of_the_same_bvh)"},
                "stage_ms": {k: round(v, 4) for k, v in acc.items()},
-               "note": "the 70 MB scene is cache resident (round-1 counters: L1 hit rate 84 %, L2 79 %), so HBM is not what binds these kernels: vector-"
-                       "instruction issue and the vector L1's access rate do (DESIGN.md section 8)"}
+               "note": ("the scene (%.0f MB of nodes, triangles and materials) exceeds the 256 MiB Infinity Cache: the fabric-side bytes of `traffic` are HBM bytes"
+                        % (self.n_tris * 80e-6 + st["n_nodes"] * 80e-6)) if self.n_tris * 80 + st["n_nodes"] * 80 > (256 << 20) else
+                       "the 70 MB scene is cache resident (L1 hit rate 84 %, L2 80 %), so HBM is not what binds these kernels: vector-instruction issue "
+                       "does (roofline.valu_issue), with the vector L1's access rate close behind (DESIGN.md section 8)"}
         pin = self._pinned()
         if pin:  # N_node / N_tri counted by oracle B's instrumented traversal (its own BVH2, <= 4-triangle leaves), all rays
             n_rays = pin["camera_rays"] + pin["bounce_rays"] + pin["shadow_rays"]
@@ -583,10 +637,37 @@ class TerrainWorkload(TriWorkload):
         return d
 
 
-WORKLOADS = {SpheresWorkload.name: SpheresWorkload, TriWorkload.name: TriWorkload, TerrainWorkload.name: TerrainWorkload}
+class Tri16mWorkload(TriWorkload):
+    """Context workload, not a BASELINE config: the headline soup with 16 M triangles - 320 MB of BVH nodes, 768 MB of triangle
+    records, 512 MB of materials - so the scene is six times the 256 MiB Infinity Cache and the L2-miss bytes the counters
+    see ARE HBM traffic: the one workload on which "fraction of the HBM roofline" can be judged from counters.  Same
+    generator, camera, resolution, spp and bounce count; edges scaled by 16^(-1/3) so the rays meet as much surface."""
+
+    name = "tri16m_1080p_4spp"
+    n_tris, edge = 16_000_000, 0.032
+
+    def cpu_baseline(self):  # bounded sample: the oracle's BVH2 over 16 M triangles alone takes a while
+        threads = host_threads()
+        sc = self._oracle()
+        rows = (self.height // 2 - 32, self.height // 2 + 32)
+        t0 = time.perf_counter()
+        _, ct = sc.render(self.width, self.height, spp=self.spp, bounces=self.bounces, seed=self.seed, sky=self.sky, rot=self.rot, pos=self.pos, rows=rows,
+                          threads=threads)
+        dt = time.perf_counter() - t0
+        rays = ct["camera_rays"] + ct["bounce_rays"] + ct["shadow_rays"]
+        return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                "sample": f"rows {rows[0]}..{rows[1]} of the frame at {self.spp} spp, oracle B (OpenMP, {threads} threads), {rays} rays in {dt:.2f} s"}
+
+
+WORKLOADS = {SpheresWorkload.name: SpheresWorkload, TriWorkload.name: TriWorkload, TerrainWorkload.name: TerrainWorkload, Tri16mWorkload.name: Tri16mWorkload}
 
 
 def main():
+    # dmabuf IPC: the host driver of this pool supports nothing else, and without it RCCL / device-memory sharing across
+    # processes fails with "hipIpcGetMemHandle: invalid argument" (task environment notes; exported on the boxes already).
+    # Set before anything imports torch or opens the GPU, so both launch modes - this file's own launcher and
+    # torch.distributed.run - run their ranks in the same environment.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # plain `python bench.py --gpus N`: this process only launches the ranks
         raise SystemExit(launch_ranks(args.gpus))
@@ -644,6 +725,8 @@ def main():
         ln.r = r if li == 0 else R.Renderer(local_rank)
         ln.wl = wl if li == 0 else WORKLOADS[args.workload](R, ln.r)
         ln.r.set_partition(rank, world)
+        if hasattr(ln.wl, "set_share"):
+            ln.wl.set_share(world, n_lanes)
         ln.frame = torch.empty((wl.height, wl.width, 3), dtype=torch.float32, device=dev)
         if multi:
             ln.mine = torch.zeros((tiles_per_rank, T, T, 3), dtype=torch.float32, device=dev)
@@ -740,6 +823,8 @@ def main():
             rl = wl.roofline()
             tr = None if args.no_traffic else measure_traffic(args.workload, wl.dominant_kernel)
             out["roofline"] = finish_roofline(rl, tr)
+            if not args.no_traffic and isinstance(wl, TriWorkload):  # the bound the per-lane traversal kernels actually run into
+                out["roofline"]["valu_issue"] = measure_valu_issue(args.workload, wl.dominant_kernel)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = wl.cpu_baseline()
                 if getattr(wl, "fp32_ops_per_step", None):  # path A: the roofline that means something for it

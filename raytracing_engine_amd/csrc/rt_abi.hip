@@ -9,6 +9,7 @@
 #include <new>
 
 #include "rt_internal.h"
+#include "rt_roctx.h"
 
 using rt::Ctx;
 
@@ -144,6 +145,7 @@ int enqueue_samples(Ctx* c, const float rot[4], const float pos[3], uint32_t s0,
             fp.level_w[i] = c->dims[i][0];
             fp.level[i] = c->d_level[i];
         }
+        rt::RoctxRange rr("rt.path_a.pyramid_fused");
         if (stage_events) RT_HIP(c, hipEventRecord(c->ev_stage[ev++], c->stream));
         if (int rc = rt::launch_pyramid_fused(c, spheres, c->scene.objCount, fp)) return rc;
     } else {
@@ -171,6 +173,7 @@ int enqueue_samples(Ctx* c, const float rot[4], const float pos[3], uint32_t s0,
             p.parent_stride = i ? c->dims[i - 1][0] * c->dims[i - 1][1] : 0;
             p.alg = c->cfg.march_algorithm ? c->cfg.march_algorithm : 3u;
             std::memcpy(p.repeat, c->cfg.repeat, sizeof p.repeat);
+            rt::RoctxRange rr("rt.path_a.cone_level", i);
             if (stage_events) RT_HIP(c, hipEventRecord(c->ev_stage[ev++], c->stream));
             int rc = rt::launch_cone_level(c, spheres, c->scene.objCount, p, i ? c->d_level[i - 1] : nullptr, c->d_level[i], nb);
             if (rc) return rc;
@@ -203,7 +206,11 @@ int enqueue_samples(Ctx* c, const float rot[4], const float pos[3], uint32_t s0,
     std::memcpy(sp.repeat, c->cfg.repeat, sizeof sp.repeat);
     sp.reflections = c->cfg.reflections;
     sp.reflectivity = c->cfg.reflectivity;
-    int rc = rt::launch_shade(c, set, c->scene.objCount, sp, c->d_level[count - 1], dst, c->d_counters);
+    int rc;
+    {
+        rt::RoctxRange rr("rt.path_a.shade");
+        rc = rt::launch_shade(c, set, c->scene.objCount, sp, c->d_level[count - 1], dst, c->d_counters);
+    }
     if (rc) return rc;
     if (stage_events) RT_HIP(c, hipEventRecord(c->ev_stage[ev++], c->stream));
     c->last_image = nb - 1u;

@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "rt_internal.h"
+#include "rt_roctx.h"
 
 using rt::Ctx;
 
@@ -118,6 +119,7 @@ int rt_gather_tiles(rt_ctx* ctx, const void* tiles_dev, void* gathered_dev, uint
     if (!tiles_dev || tiles_per_rank == 0) return c->fail(RT_ERR_INVALID, "NULL tile buffer or tiles_per_rank = 0");
     if (c->comm_rank == 0 && !gathered_dev) return c->fail(RT_ERR_INVALID, "rank 0 needs the gather buffer");
     if (!c->width) return c->fail(RT_ERR_STATE, "rt_resize has not been called");
+    rt::RoctxRange rr("rt.gather_tiles");
     // Every rank sends exactly the tiles it owns (tiles_dev holds `owned` tiles, as rt_render*_device(tile_major)
     // documents: with 510 tiles on 8 ranks, ranks 6 and 7 own 63, not ceil(510/8) = 64) and the root receives
     // each peer's own count into that peer's block of tiles_per_rank tiles; pad tiles are never touched.

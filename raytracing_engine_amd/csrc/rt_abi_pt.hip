@@ -12,6 +12,7 @@
 
 #include "bvh_build.h"
 #include "rt_internal.h"
+#include "rt_roctx.h"
 
 using rt::Ctx;
 using rt::PtData;
@@ -225,6 +226,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     const uint32_t grid_stride = (uint32_t)c->n_cus * 2u;  // 1024-thread workgroups, grid-stride
 
     StageTimer tm{c, c->cfg.profile_stages != 0, pt.ev_pool, {}, 0};
+    rt::RoctxRange frame_range("rt.path_b.frame");
 
     RT_HIP(c, hipMemsetAsync(pt.d_stats, 0, kStatWords * sizeof(unsigned long long), c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
@@ -273,6 +275,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         // fixed LDS array: a tree that may need more (a deep two-level tree) takes the per-lane kernel, whose stack is sized from stack_need
         const bool packet = !prm->tune_no_packet && pt.stack_need <= rt::kPacketStackEntries;
         if (!packet) {
+            rt::RoctxRange rr("rt.path_b.generate");
             tm.begin(0);
             if (int rc = rt::launch_pt_generate(c, f, pt.st, pt.d_queue[0], pt.d_ctr)) return rc;
             tm.end();
@@ -283,6 +286,8 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             uint32_t* ctr_n = pt.d_ctr + (size_t)rt::PT_CTR_STRIDE * (d + 1);
             const uint32_t* q = pt.d_queue[d & 1];
             uint32_t* qn = pt.d_queue[(d + 1) & 1];
+            {
+            rt::RoctxRange rr(d == 0 && packet ? "rt.path_b.trace_packet depth" : shadow_deferred ? "rt.path_b.trace_fused depth" : "rt.path_b.trace_closest depth", d);
             tm.begin(d == 0 && packet ? 5 : shadow_deferred ? 6 : 1);
             if (d == 0 && packet) {  // camera rays: one shared origin, coherent 4x4-pixel blocks per wave
                 if (int rc = rt::launch_pt_trace_packet(c, sc, f, pt.st, pt.d_stats, count)) return rc;
@@ -297,14 +302,18 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
                 return rc;
             }
             tm.end();
+            }
             launches_closest++;
             if (shadow_pending) {  // shade(d) adds sky/emission after shadow(d-1)'s contribution
                 RT_HIP(c, hipStreamWaitEvent(c->stream, pt.ev_shadowed, 0));
                 shadow_pending = false;
             }
-            tm.begin(2);
-            if (int rc = rt::launch_pt_shade(c, sc, f, pt.st, d == 0 && packet ? nullptr : q, ctr_d + rt::PT_CTR_COUNT, d, qn, ctr_n, grid_stride, prm->tune_sort_rays != 0)) return rc;
-            tm.end();
+            {
+                rt::RoctxRange rr("rt.path_b.shade depth", d);
+                tm.begin(2);
+                if (int rc = rt::launch_pt_shade(c, sc, f, pt.st, d == 0 && packet ? nullptr : q, ctr_d + rt::PT_CTR_COUNT, d, qn, ctr_n, grid_stride, prm->tune_sort_rays != 0)) return rc;
+                tm.end();
+            }
             if (pt.n_lights) {
                 if (fused && d < prm->bounces) {  // goes into the same launch as closest(d + 1)
                     shadow_deferred = true;
@@ -320,9 +329,13 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
                     RT_HIP(c, hipStreamWaitEvent(c->aux_stream, pt.ev_shaded, 0));
                     c->stream = c->aux_stream;
                 }
-                tm.begin(3);
-                int rc = rt::launch_pt_trace(c, sc, pt.st, nullptr, ctr_n + rt::PT_CTR_SHADOW_COUNT, ctr_n + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, true, count, grid_persistent, sk2, refill_min, tri_mode, tri_cfg);
-                tm.end();
+                int rc;
+                {
+                    rt::RoctxRange rr("rt.path_b.trace_shadow depth", d);
+                    tm.begin(3);
+                    rc = rt::launch_pt_trace(c, sc, pt.st, nullptr, ctr_n + rt::PT_CTR_SHADOW_COUNT, ctr_n + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, true, count, grid_persistent, sk2, refill_min, tri_mode, tri_cfg);
+                    tm.end();
+                }
                 if (overlap) {
                     hipError_t e = rc ? hipSuccess : hipEventRecord(pt.ev_shadowed, c->aux_stream);
                     c->stream = main_stream;
@@ -337,9 +350,12 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             RT_HIP(c, hipStreamWaitEvent(c->stream, pt.ev_shadowed, 0));
             shadow_pending = false;
         }
-        tm.begin(4);
-        if (int rc = rt::launch_pt_resolve(c, f, pt.st, pt.d_acc, dst_dev, tile_major)) return rc;
-        tm.end();
+        {
+            rt::RoctxRange rr("rt.path_b.resolve");
+            tm.begin(4);
+            if (int rc = rt::launch_pt_resolve(c, f, pt.st, pt.d_acc, dst_dev, tile_major)) return rc;
+            tm.end();
+        }
         if (sync) {  // ray counters of this batch (the copy is ordered after the kernels on the stream)
             RT_HIP(c, hipMemcpyAsync(h_ctr.data(), pt.d_ctr, ctr_words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             RT_HIP(c, hipStreamSynchronize(c->stream));

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-rank cost of a 1/N tile share of the headline frame on ONE GPU (rank 0 of N emulated with
 rt_set_partition), for 1 .. --lanes frames in flight (contexts taking the frames round-robin, as bench.py
-does): what strong scaling can reach before the exchange.   python tools/partition_scaling.py [--lanes 6]"""
+does), INCLUDING rank 0's de-tile of a full (N, tiles_per_rank, 64, 64, 3) gather buffer on the lane's stream after
+every frame: what strong scaling can reach before the xGMI transfer itself (25 MB per frame into rank 0, which one
+GPU cannot emulate).   python tools/partition_scaling.py [--lanes 6] [--no-detile]"""
 import argparse
 import os
 import sys
@@ -15,6 +17,8 @@ import raytracing_engine_amd as R  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=6)
 ap.add_argument("--frames", type=int, default=24)
+ap.add_argument("--no-detile", action="store_true")
+ap.add_argument("--tune", default="", help="k=v,k=v tuning knobs of rt_pt_params")
 a = ap.parse_args()
 mesh = R.scenes.soup_scene(1_000_000, seed=1, edge=0.08)
 rs, bufs = [], []
@@ -24,19 +28,30 @@ for _ in range(a.lanes):
     r.resize(1920, 1080)
     rs.append(r)
     bufs.append(torch.empty(1920 * 1088 * 3 + 64 * 64 * 3 * 600, dtype=torch.float32, device="cuda"))
-prm = rs[0].pt_params(spp=4, bounces=1, seed=1, sky=(0.2, 0.2, 0.25))
+tiles = 30 * 17
+gathered = [torch.zeros(8 * 64 * 64 * 64 * 3, dtype=torch.float32, device="cuda") for _ in range(a.lanes)]  # room for (N, ceil(510 / N), 64, 64, 3), N <= 8
+frames = [torch.empty(1920 * 1080 * 3, dtype=torch.float32, device="cuda") for _ in range(a.lanes)]
+tune = dict((k, int(v, 0)) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv))
+prm = rs[0].pt_params(spp=4, bounces=1, seed=1, sky=(0.2, 0.2, 0.25), **tune)
+
+
+def frame(i, lanes, n_ranks):
+    k = i % lanes
+    rs[k].render_pt_device((0, 0, 0, 1), (0, 0, 0), prm, bufs[k].data_ptr(), True)
+    if not a.no_detile:
+        rs[k].detile_device(gathered[k].data_ptr(), n_ranks, -(-tiles // n_ranks), frames[k].data_ptr())
 
 
 def run(lanes, n_ranks):
     for r in rs:
         r.set_partition(0, n_ranks)
     for i in range(2 * lanes):
-        rs[i % lanes].render_pt_device((0, 0, 0, 1), (0, 0, 0), prm, bufs[i % lanes].data_ptr(), True)
+        frame(i, lanes, n_ranks)
     for r in rs:
         r.synchronize()
     t0 = time.perf_counter()
     for i in range(a.frames):
-        rs[i % lanes].render_pt_device((0, 0, 0, 1), (0, 0, 0), prm, bufs[i % lanes].data_ptr(), True)
+        frame(i, lanes, n_ranks)
     for r in rs:
         r.synchronize()
     return (time.perf_counter() - t0) / a.frames * 1e3
