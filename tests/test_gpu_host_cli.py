@@ -94,3 +94,29 @@ def test_sketched_variants_and_frames_in_flight(exe, tmp_path):
     ref8 = O.to_unorm8(O.render_a(O.default_scene(), 160, 96)["rgb"])[::-1, :, :3]
     diff = np.abs(read_ppm(b).astype(np.int16) - ref8.astype(np.int16))
     assert diff.max() <= 1 and np.count_nonzero(diff) <= 0.001 * diff.size
+
+
+def test_roctx_ranges_are_pushed_and_change_nothing(tmp_path):
+    """RT_ROCTX=1 makes the library bracket every stage launch with a roctx range (csrc/rt_roctx.h; the marker library is opened
+    with dlopen on first use): the frames of both paths must be what they are without it, and the marker library must really be
+    in the process (otherwise the ranges were silently off)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np\n"
+        "import raytracing_engine_amd as R\n"
+        "r = R.Renderer(0)\n"
+        "r.set_scene(R.default_scene()); r.resize(160, 96)\n"
+        "a = r.render(spp=4)\n"
+        "r.set_mesh(*R.scenes.cornell_tri_scene())\n"
+        "b = r.render_pt(pos=(0, 1, 0), spp=2, bounces=2, seed=3)\n"
+        "np.savez(sys.argv[1], a=a, b=b, roctx=np.array('roctx' in open('/proc/self/maps').read()))\n"
+    )
+    out = {}
+    for flag in ("0", "1"):
+        path = tmp_path / f"frames_{flag}.npz"
+        subprocess.run([sys.executable, "-c", code, str(path)], check=True, env=dict(os.environ, RT_ROCTX=flag), cwd=ROOT)
+        out[flag] = np.load(path)
+    assert bool(out["1"]["roctx"]) and not bool(out["0"]["roctx"])
+    assert np.array_equal(out["0"]["a"], out["1"]["a"]) and np.array_equal(out["0"]["b"], out["1"]["b"])
