@@ -8,7 +8,7 @@
 //
 //   rt_host [--size WxH] [--yaw R] [--pitch R] [--pos x,y,z] [--move right,forward,up] [--spp N]
 //           [--scene default|soup:N] [--two-level] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm]
-//           [--march 1|2|3] [--repeat x,y,z] [--mirror N[,reflectivity]] [--inflight K]
+//           [--march 1|2|3] [--repeat x,y,z] [--mirror N[,reflectivity]] [--transmit N[,transparency[,index]]] [--inflight K]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -107,7 +107,8 @@ int main(int argc, char** argv) {
     std::string scene = "default", out = "frame.ppm";
     uint32_t march = 0, inflight = 0, mirror = 0;
     bool two_level = false;  // soup scenes: top-level BVH over 64 bottom-level chunks (rt_set_mesh_ex)
-    float repeat[3] = {0, 0, 0}, reflectivity = 0.5f;
+    float repeat[3] = {0, 0, 0}, reflectivity = 0.5f, transparency = 0.5f, refraction_index = 1.0f;
+    unsigned transmit = 0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -125,12 +126,13 @@ int main(int argc, char** argv) {
         else if (a == "--march") march = (uint32_t)std::atoi(next());
         else if (a == "--repeat") std::sscanf(next(), "%f,%f,%f", &repeat[0], &repeat[1], &repeat[2]);
         else if (a == "--mirror") std::sscanf(next(), "%u,%f", &mirror, &reflectivity);
+        else if (a == "--transmit") std::sscanf(next(), "%u,%f,%f", &transmit, &transparency, &refraction_index);
         else if (a == "--two-level") two_level = true;
         else if (a == "--inflight") inflight = (uint32_t)std::atoi(next());
         else {
             std::fprintf(stderr, "usage: rt_host [--size WxH] [--yaw R] [--pitch R] [--pos x,y,z] [--move r,f,u] [--spp N] "
                                  "[--scene default|soup:N] [--two-level] [--bounces N] [--seed N] [--frames N] [--out file.ppm|file.pfm] "
-                                 "[--march 1|2|3] [--repeat x,y,z] [--mirror N[,reflectivity]] [--inflight K]\n");
+                                 "[--march 1|2|3] [--repeat x,y,z] [--mirror N[,reflectivity]] [--transmit N[,transparency[,index]]] [--inflight K]\n");
             return 2;
         }
     }
@@ -173,13 +175,16 @@ int main(int argc, char** argv) {
         rt_mutable_data s;
         rt_default_scene(&s);  // src/main.rs:524-591
         if ((rc = rt_set_scene(ctx, &s, sizeof s))) return fail(ctx, "rt_set_scene", rc);
-        if (march || mirror || repeat[0] > 0 || repeat[1] > 0 || repeat[2] > 0) {  // the march loops / repeat() / reflections the author sketched
+        if (march || mirror || transmit || repeat[0] > 0 || repeat[1] > 0 || repeat[2] > 0) {  // the march loops / repeat() / reflections the author sketched
             rt_config cfg;
             rt_default_config(&cfg);
             cfg.march_algorithm = march;
             for (int a = 0; a < 3; a++) cfg.repeat[a] = repeat[a];
             cfg.reflections = mirror;
             cfg.reflectivity = reflectivity;
+            cfg.transmissions = transmit;  // fragment.glsl:124 / :126: transparency (index 1) or refraction (index > 1)
+            cfg.transparency = transparency;
+            cfg.refraction_index = refraction_index;
             if ((rc = rt_set_config(ctx, &cfg))) return fail(ctx, "rt_set_config", rc);
         }
     }

@@ -97,13 +97,25 @@ typedef struct rt_config {
                                  P + r * max(len, 0) is shaded by fragment.glsl:144-186 with P as the eye and added with
                                  weight prod(reflectivity * mat.specular) over the surfaces passed */
     float reflectivity;       /* 0..1, default 0.5 (mat.specular, which the reference never reads, scales it per material) */
+    uint32_t transmissions;   /* spheres a transmitted ray may cross, 0..8 (shaders/fragment.glsl:124 "TODO: transparency", :126 "TODO:
+                                 refraction"; build-defined): after shading a hit P on sphere S seen along I (outward normal n) the ray
+                                 enters S - straight on for refraction_index == 1, else T = normalize(refract(I, n, 1 / index)) -
+                                 crosses it to the far side in closed form (oc = domain(P) - S.pos, b = oc.T,
+                                 disc = b*b - (oc.oc - S.size^2), t = max(disc > 0 ? sqrt(disc) - b : 0, 0), Q = P + T t), leaves along
+                                 D = T or normalize(refract(T, -n2, index)) with n2 = normalize(oc + T t) (total internal reflection
+                                 ends the chain), and is marched like a mirror ray: len = 1 + traceCone(Q + D, D, RAY_RADIUS); a hit at
+                                 Q + D * max(len, 0) is shaded by fragment.glsl:144-186 with Q as the eye and added with weight
+                                 prod(transparency * mat.diffuse) over the surfaces passed.  Starts at the camera ray's hit,
+                                 independent of the mirror chain.  Needs fuse_levels = 0 only as far as march_algorithm / repeat do. */
+    float transparency;       /* 0..1, default 0.5 (mat.diffuse, which the reference never reads, scales it per material: 1 in its scene) */
+    float refraction_index;   /* 1..4, default 1 = straight through (transparency); > 1 bends the ray at both surfaces (refraction) */
 } rt_config;
 
 typedef struct rt_stats {
     uint32_t width, height, level_count, spp;
     uint64_t frames;           /* rt_render* calls since rt_resize */
     uint64_t primary_rays;     /* last call: width*height*spp (owned tiles only) */
-    uint64_t shadow_rays;      /* last call: lightCount per shaded surface point (hit pixel samples + reflection hits) */
+    uint64_t shadow_rays;      /* last call: lightCount per shaded surface point (hit pixel samples + reflection / transmission hits) */
     uint64_t hit_pixels;       /* last call */
     uint64_t cone_threads;     /* last call: compute-stage invocations over all levels */
     float    ms_total;         /* last call: HIP-event time around the whole stage loop */
@@ -112,6 +124,7 @@ typedef struct rt_stats {
     float    ms_level[RT_MAX_LEVELS]; /* last call, last sample (profile_stages=1, fuse_levels=0 only) */
     float    ms_fused;         /* last call, last sample: the one-launch pyramid kernel (profile_stages=1, fuse_levels=1) */
     uint64_t reflection_rays;  /* last call: mirror rays marched (rt_config.reflections > 0) */
+    uint64_t transmission_rays; /* last call: rays marched behind a crossed sphere (rt_config.transmissions > 0) */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -48,12 +48,13 @@ class Scene(C.Structure):
 class Config(C.Structure):
     _fields_ = [("render_dist", C.c_float), ("cam_fall_off", C.c_float), ("light_fall_off", C.c_float),
                 ("ray_radius", C.c_float), ("max_steps", C.c_uint32), ("march_algorithm", C.c_uint32), ("repeat", C.c_float * 3),
-                ("reflections", C.c_uint32), ("reflectivity", C.c_float)]
+                ("reflections", C.c_uint32), ("reflectivity", C.c_float),
+                ("transmissions", C.c_uint32), ("transparency", C.c_float), ("refraction_index", C.c_float)]
 
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("cone_threads", "cone_steps", "cone_sdf", "hit_pixels",
-                                          "shadow_rays", "shadow_steps", "shadow_sdf", "reflection_rays")]
+                                          "shadow_rays", "shadow_steps", "shadow_sdf", "reflection_rays", "transmission_rays")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

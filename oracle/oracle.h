@@ -68,6 +68,20 @@ typedef struct {
      * prod(reflectivity * mat.specular) over the surfaces passed; at most `reflections` bounces. */
     uint32_t reflections;
     float reflectivity;
+    /* transmission (fragment.glsl:124 "TODO: transparency", :126 "TODO: refraction"; build-defined): 0 = off =
+     * the reference as shipped.  After shading a hit point P on sphere S seen along the unit direction I (outward normal n):
+     * the ray enters the sphere - straight on for refraction_index == 1 (transparency), bent by Snell's law otherwise
+     * (T = normalize(refract(I, n, 1 / index)), GLSL's refract) - and crosses it to the far side in closed form:
+     * oc = domain(P) - S.pos, b = oc.T, disc = b*b - (oc.oc - S.size^2), t = disc > 0 ? sqrt(disc) - b : 0, clamped at 0,
+     * Q = P + T t.  There it leaves along D = T (transparency) or D = normalize(refract(T, -n2, index)) with
+     * n2 = normalize(oc + T t); total internal reflection (k < 0) ends the chain.  From Q the scene is marched like a mirror
+     * ray: len = 1 + traceCone(Q + D, D, RAY_RADIUS) (compute.glsl:44-66); a hit (len < RENDER_DIST) at Q + D * max(len, 0) is
+     * shaded by fragment.glsl:144-186 with Q as the eye and added with weight prod(transparency * mat.diffuse) over the
+     * surfaces passed (mat.diffuse is a field the reference uploads and never reads; 1 in its scene); at most `transmissions`
+     * spheres are crossed.  The chain starts at the camera ray's hit and is independent of the mirror chain. */
+    uint32_t transmissions;
+    float transparency;      /* 0..1, default 0.5 */
+    float refraction_index;  /* >= 1, default 1 (straight through) */
 } ora_config;
 
 typedef struct {
@@ -79,6 +93,7 @@ typedef struct {
     uint64_t shadow_steps;  /* iterations of fragment.glsl:99-119 */
     uint64_t shadow_sdf;    /* sphereSDF evaluations inside shadowRay */
     uint64_t reflection_rays; /* mirror rays marched (reflections > 0) */
+    uint64_t transmission_rays; /* rays marched behind a crossed sphere (transmissions > 0) */
 } ora_counters;
 
 void ora_default_config(ora_config* cfg);

@@ -71,6 +71,9 @@ void ora_default_config(ora_config* cfg) {
     cfg->repeat[0] = cfg->repeat[1] = cfg->repeat[2] = 0.0f;
     cfg->reflections = 0;    /* the reference has none (fragment.glsl:125 is a TODO) */
     cfg->reflectivity = 0.5f;
+    cfg->transmissions = 0;  /* the reference has none (fragment.glsl:124,126 are TODOs) */
+    cfg->transparency = 0.5f;
+    cfg->refraction_index = 1.0f;
 }
 
 /* src/main.rs:524-591 */
@@ -291,8 +294,14 @@ static inline float cone_pixel(const ora_scene* sc, const ora_config* cfg, uint3
 
 /* ---- shaders/fragment.glsl:144-186: nearest sphere, material, light loop for surface point `position` seen from `eye`
  * along the unit direction `step` (for the camera ray eye = push_constants.pos; for a mirror bounce the previous hit) ---- */
-static inline void shade_point(const ora_scene* sc, const ora_config* cfg, v3 position, v3 eye, v3 step, float out[3], v3* normal_out,
-                               float* specular_out, ora_counters* ct) {
+typedef struct {
+    v3 normal;
+    float specular, diffuse;   /* mat.specular / mat.diffuse of the surface: per-material scales of the mirror / transmission chains */
+    const ora_object* object;
+} surface_t;
+
+static inline void shade_point(const ora_scene* sc, const ora_config* cfg, v3 position, v3 eye, v3 step, float out[3], surface_t* surf,
+                               ora_counters* ct) {
     /* :144-156 nearest sphere, strict '<', material index = object index */
     uint32_t best = 0;
     float dist = sphere_sdf(position, &sc->objs[0], cfg);
@@ -341,8 +350,10 @@ static inline void shade_point(const ora_scene* sc, const ora_config* cfg, v3 po
         b = fmaf(((mat->ambient + db) / cam_fall) * normal_fall, mat->color[2], b);
     }
     out[0] = r; out[1] = g; out[2] = b;
-    *normal_out = normal;
-    *specular_out = mat->specular;
+    surf->normal = normal;
+    surf->specular = mat->specular;
+    surf->diffuse = mat->diffuse;
+    surf->object = object;
 }
 
 /* ---- shaders/fragment.glsl:127-187 main, one invocation -------------------------------- */
@@ -361,28 +372,78 @@ static inline void shade_pixel(const ora_scene* sc, const ora_config* cfg, uint3
     ct->hit_pixels++;
 
     v3 position = v3_fma(step, total_dist, pos); /* :142 */
-    v3 normal;
-    float specular;
-    shade_point(sc, cfg, position, pos, step, out, &normal, &specular, ct);
+    surface_t first;
+    shade_point(sc, cfg, position, pos, step, out, &first, ct);
+    const v3 first_position = position, first_step = step;
 
     /* mirror reflections - build-defined (fragment.glsl:125 is a TODO), specified at ora_config.reflections in oracle.h */
     float weight = 1.0f;
+    surface_t surf = first;
     for (uint32_t bounce = 0; bounce < cfg->reflections; bounce++) {
-        weight *= cfg->reflectivity * specular;
-        const float k = 2.0f * v3_dot(normal, step);
-        const v3 r = v3_make(fmaf(-k, normal.x, step.x), fmaf(-k, normal.y, step.y), fmaf(-k, normal.z, step.z)); /* reflect(step, normal) */
+        weight *= cfg->reflectivity * surf.specular;
+        const float k = 2.0f * v3_dot(surf.normal, step);
+        const v3 r = v3_make(fmaf(-k, surf.normal.x, step.x), fmaf(-k, surf.normal.y, step.y), fmaf(-k, surf.normal.z, step.z)); /* reflect(step, normal) */
         uint64_t dummy_steps = 0, dummy_sdf = 0;
         ct->reflection_rays++;
         const float len = 1.0f + trace_cone3(sc, cfg, v3_add(position, r), r, cfg->ray_radius, &dummy_steps, &dummy_sdf);
         if (!(len < cfg->render_dist)) break;
         const v3 hit = v3_fma(r, fmaxf(len, 0.0f), position);
         float rgb[3];
-        shade_point(sc, cfg, hit, position, r, rgb, &normal, &specular, ct);
+        shade_point(sc, cfg, hit, position, r, rgb, &surf, ct);
         out[0] = fmaf(weight, rgb[0], out[0]);
         out[1] = fmaf(weight, rgb[1], out[1]);
         out[2] = fmaf(weight, rgb[2], out[2]);
         position = hit;
         step = r;
+    }
+
+    /* transmission - build-defined (fragment.glsl:124 "TODO: transparency", :126 "TODO: refraction"), specified at
+     * ora_config.transmissions in oracle.h; starts again at the camera ray's hit */
+    weight = 1.0f;
+    surf = first;
+    v3 P = first_position, I = first_step;
+    const float idx = cfg->refraction_index;
+    const int bend = idx != 1.0f;
+    for (uint32_t pass = 0; pass < cfg->transmissions; pass++) {
+        weight *= cfg->transparency * surf.diffuse;
+        v3 T = I;
+        if (bend) { /* T = normalize(refract(I, n, 1 / index)) */
+            const float eta = 1.0f / idx;
+            const float ci = v3_dot(surf.normal, I);
+            const float k = fmaf(-(eta * eta), fmaf(-ci, ci, 1.0f), 1.0f);
+            if (k < 0.0f) break;
+            const float s = fmaf(eta, ci, sqrtf(k));
+            T = v3_normalize(v3_make(fmaf(-s, surf.normal.x, eta * I.x), fmaf(-s, surf.normal.y, eta * I.y), fmaf(-s, surf.normal.z, eta * I.z)));
+        }
+        /* across the sphere to its far side, in closed form */
+        const v3 oc = v3_sub(domain(P, cfg), v3_load(surf.object->pos));
+        const float b = v3_dot(oc, T);
+        const float cc = fmaf(-surf.object->size, surf.object->size, v3_dot(oc, oc));
+        const float disc = fmaf(b, b, -cc);
+        float t = disc > 0.0f ? sqrtf(disc) - b : 0.0f;
+        if (!(t > 0.0f)) t = 0.0f;
+        const v3 Q = v3_fma(T, t, P);
+        v3 D = T;
+        if (bend) { /* D = normalize(refract(T, -n2, index)), n2 = outward normal at the exit point */
+            const v3 n2 = v3_normalize(v3_fma(T, t, oc));
+            const float ce = v3_dot(n2, T);
+            const float k2 = fmaf(-(idx * idx), fmaf(-ce, ce, 1.0f), 1.0f);
+            if (k2 < 0.0f) break; /* total internal reflection */
+            const float s2 = fmaf(-idx, ce, sqrtf(k2));
+            D = v3_normalize(v3_make(fmaf(s2, n2.x, idx * T.x), fmaf(s2, n2.y, idx * T.y), fmaf(s2, n2.z, idx * T.z)));
+        }
+        uint64_t dummy_steps = 0, dummy_sdf = 0;
+        ct->transmission_rays++;
+        const float len = 1.0f + trace_cone3(sc, cfg, v3_add(Q, D), D, cfg->ray_radius, &dummy_steps, &dummy_sdf);
+        if (!(len < cfg->render_dist)) break;
+        const v3 hit = v3_fma(D, fmaxf(len, 0.0f), Q);
+        float rgb[3];
+        shade_point(sc, cfg, hit, Q, D, rgb, &surf, ct);
+        out[0] = fmaf(weight, rgb[0], out[0]);
+        out[1] = fmaf(weight, rgb[1], out[1]);
+        out[2] = fmaf(weight, rgb[2], out[2]);
+        P = hit;
+        I = D;
     }
 }
 
@@ -436,17 +497,17 @@ int ora_render_a(const ora_scene* scene, const ora_config* cfg, uint32_t width, 
     }
     /* src/main.rs:318-338: full-screen draw, fragment shader reads the last level */
     if (rgb) {
-        uint64_t hit = 0, srays = 0, ssteps = 0, ssdf = 0, rrays = 0;
-#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : hit, srays, ssteps, ssdf, rrays)
+        uint64_t hit = 0, srays = 0, ssteps = 0, ssdf = 0, rrays = 0, trays = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : hit, srays, ssteps, ssdf, rrays, trays)
         for (uint32_t py = 0; py < height; py++) {
             ora_counters ct;
             memset(&ct, 0, sizeof ct);
             for (uint32_t px = 0; px < width; px++)
                 shade_pixel(scene, cfg, px, py, view, ratio, rot, p, jitter, prev[(size_t)py * prev_w + px],
                             rgb + ((size_t)py * width + px) * 3, &ct);
-            hit += ct.hit_pixels; srays += ct.shadow_rays; ssteps += ct.shadow_steps; ssdf += ct.shadow_sdf; rrays += ct.reflection_rays;
+            hit += ct.hit_pixels; srays += ct.shadow_rays; ssteps += ct.shadow_steps; ssdf += ct.shadow_sdf; rrays += ct.reflection_rays; trays += ct.transmission_rays;
         }
-        total.hit_pixels = hit; total.shadow_rays = srays; total.shadow_steps = ssteps; total.shadow_sdf = ssdf; total.reflection_rays = rrays;
+        total.hit_pixels = hit; total.shadow_rays = srays; total.shadow_steps = ssteps; total.shadow_sdf = ssdf; total.reflection_rays = rrays; total.transmission_rays = trays;
     }
     free(prev);
     if (counters) *counters = total;

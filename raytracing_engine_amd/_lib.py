@@ -43,7 +43,8 @@ class MutableData(C.Structure):  # shaders/compute.glsl:17-24, 656 B
 class Config(C.Structure):
     _fields_ = [("render_dist", C.c_float), ("cam_fall_off", C.c_float), ("light_fall_off", C.c_float),
                 ("ray_radius", C.c_float), ("max_steps", C.c_uint32), ("profile_stages", C.c_uint32), ("fuse_levels", C.c_uint32),
-                ("march_algorithm", C.c_uint32), ("repeat", C.c_float * 3), ("reflections", C.c_uint32), ("reflectivity", C.c_float)]
+                ("march_algorithm", C.c_uint32), ("repeat", C.c_float * 3), ("reflections", C.c_uint32), ("reflectivity", C.c_float),
+                ("transmissions", C.c_uint32), ("transparency", C.c_float), ("refraction_index", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -51,7 +52,7 @@ class Stats(C.Structure):
                 ("frames", C.c_uint64), ("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("hit_pixels", C.c_uint64), ("cone_threads", C.c_uint64), ("ms_total", C.c_float),
                 ("ms_cone", C.c_float), ("ms_shade", C.c_float), ("ms_level", C.c_float * RT_MAX_LEVELS), ("ms_fused", C.c_float),
-                ("reflection_rays", C.c_uint64)]
+                ("reflection_rays", C.c_uint64), ("transmission_rays", C.c_uint64)]
 
     def as_dict(self):
         d = {}

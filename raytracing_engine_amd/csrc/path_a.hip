@@ -215,15 +215,20 @@ __device__ __forceinline__ float4 pick8(const float4 (&a)[8], uint32_t i) {
 // Nearest sphere, material and light loop for surface point `position` seen from `eye` along the unit direction `step`
 // (camera ray: eye = push_constants.pos; mirror bounce: the previous hit).  Returns the normal and the material's
 // specular coefficient for a following mirror bounce.
+struct Surface {  // what a following mirror / transmission step needs of the surface just shaded
+    v3 normal;
+    float specular, diffuse;  // mat.specular / mat.diffuse: per-material scales of the mirror / transmission chains (the reference reads neither)
+    float4 obj;               // the sphere: centre, radius
+};
+
 template <int N, bool REP>
-__device__ __forceinline__ void shade_point(const ShadeSet& S, const ShadeParams& p, v3 position, v3 eye, v3 step, float& r, float& g, float& b, v3& normal_out,
-                                            float& specular_out) {
+__device__ __forceinline__ void shade_point(const ShadeSet& S, const ShadeParams& p, v3 position, v3 eye, v3 step, float& r, float& g, float& b, Surface& surf) {
     // :144-156 nearest sphere (strict '<', first wins ties); material index = object index
     const Rep rep{p.repeat[0], p.repeat[1], p.repeat[2]};
     float dist = sphere_sdf<REP>(position, S.sphere[0], rep);
     float4 obj = S.sphere[0];
     float4 mat = S.mat_color_ambient[0];
-    float shine = S.mat_shine[0], specular = S.mat_specular[0];
+    float shine = S.mat_shine[0], specular = S.mat_specular[0], mat_diffuse = S.mat_diffuse[0];
 #pragma unroll
     for (int i = 1; i < N; i++) {
         const float nd = sphere_sdf<REP>(position, S.sphere[i], rep);
@@ -233,6 +238,7 @@ __device__ __forceinline__ void shade_point(const ShadeSet& S, const ShadeParams
             mat = S.mat_color_ambient[i];
             shine = S.mat_shine[i];
             specular = S.mat_specular[i];
+            mat_diffuse = S.mat_diffuse[i];
         }
     }
 
@@ -267,8 +273,10 @@ __device__ __forceinline__ void shade_point(const ShadeSet& S, const ShadeParams
         g = __builtin_fmaf(((mat.w + dg) / cam_fall) * normal_fall, mat.y, g);
         b = __builtin_fmaf(((mat.w + db) / cam_fall) * normal_fall, mat.z, b);
     }
-    normal_out = normal;
-    specular_out = specular;
+    surf.normal = normal;
+    surf.specular = specular;
+    surf.diffuse = mat_diffuse;
+    surf.obj = obj;
 }
 
 // ---- shaders/fragment.glsl:127-187 ------------------------------------------------------------
@@ -280,7 +288,7 @@ __device__ __forceinline__ void shade_point(const ShadeSet& S, const ShadeParams
 // n_points / n_refl count the shaded reflection hits and the mirror rays of this lane.
 template <int N, bool REP, bool REFL>
 __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams p, float jx, float jy, uint32_t px, uint32_t py, float total_dist, float& r,
-                                            float& g, float& b, uint32_t& n_points, uint32_t& n_refl) {
+                                            float& g, float& b, uint32_t& n_points, uint32_t& n_refl, uint32_t& n_trans) {
     r = g = b = 0.0f;
     if (!(total_dist < p.render_dist)) return false;  // :137-140
     // :129-133  gl_FragCoord.xy * 2 / cs.view - 1.0   (gl_FragCoord = pixel + 0.5)
@@ -291,28 +299,77 @@ __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams 
     v3 step = normalize(rotate_q(p.cam.rot[0], p.cam.rot[1], p.cam.rot[2], p.cam.rot[3], mk(nx, 1.0f, ny)));
     const v3 pos = mk(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
     v3 position = fma3(step, total_dist, pos);  // :142
-    v3 normal;
-    float specular;
-    shade_point<N, REP>(S, p, position, pos, step, r, g, b, normal, specular);
+    Surface first;
+    shade_point<N, REP>(S, p, position, pos, step, r, g, b, first);
     if (REFL) {
         const Rep rep{p.repeat[0], p.repeat[1], p.repeat[2]};
+        const v3 first_position = position, first_step = step;
         float weight = 1.0f;
+        Surface surf = first;
         for (uint32_t bounce = 0; bounce < p.reflections; bounce++) {
-            weight *= p.reflectivity * specular;
-            const float kk = 2.0f * dot(normal, step);
-            const v3 rd = mk(__builtin_fmaf(-kk, normal.x, step.x), __builtin_fmaf(-kk, normal.y, step.y), __builtin_fmaf(-kk, normal.z, step.z));
+            weight *= p.reflectivity * surf.specular;
+            const float kk = 2.0f * dot(surf.normal, step);
+            const v3 rd = mk(__builtin_fmaf(-kk, surf.normal.x, step.x), __builtin_fmaf(-kk, surf.normal.y, step.y), __builtin_fmaf(-kk, surf.normal.z, step.z));
             n_refl++;
             const float len = 1.0f + trace_cone<N, 3, REP>(S.sphere, position + rd, rd, p.ray_radius, p.render_dist, p.max_steps, rep);
             if (!(len < p.render_dist)) break;
             const v3 hit = fma3(rd, fmax_(len, 0.0f), position);
             float rr, rg, rb;
-            shade_point<N, REP>(S, p, hit, position, rd, rr, rg, rb, normal, specular);
+            shade_point<N, REP>(S, p, hit, position, rd, rr, rg, rb, surf);
             n_points++;
             r = __builtin_fmaf(weight, rr, r);
             g = __builtin_fmaf(weight, rg, g);
             b = __builtin_fmaf(weight, rb, b);
             position = hit;
             step = rd;
+        }
+        // transmission (fragment.glsl:124 "TODO: transparency", :126 "TODO: refraction"; build-defined, specification at
+        // rt_config.transmissions / oracle.h): enter the sphere (straight on, or bent by Snell's law), cross it to its far side in
+        // closed form, leave it, march on like a mirror ray; weight prod(transparency * mat.diffuse).  Starts at the camera ray's hit.
+        weight = 1.0f;
+        surf = first;
+        v3 P = first_position, I = first_step;
+        const float idx = p.refraction_index;
+        const bool bend = idx != 1.0f;
+        for (uint32_t pass = 0; pass < p.transmissions; pass++) {
+            weight *= p.transparency * surf.diffuse;
+            v3 T = I;
+            if (bend) {  // T = normalize(refract(I, n, 1 / index))
+                const float eta = 1.0f / idx;
+                const float ci = dot(surf.normal, I);
+                const float k = __builtin_fmaf(-(eta * eta), __builtin_fmaf(-ci, ci, 1.0f), 1.0f);
+                if (k < 0.0f) break;
+                const float sn = __builtin_fmaf(eta, ci, sqrt_cr(k));
+                T = normalize(mk(__builtin_fmaf(-sn, surf.normal.x, eta * I.x), __builtin_fmaf(-sn, surf.normal.y, eta * I.y), __builtin_fmaf(-sn, surf.normal.z, eta * I.z)));
+            }
+            const v3 oc = domain<REP>(P, rep) - mk(surf.obj.x, surf.obj.y, surf.obj.z);
+            const float bq = dot(oc, T);
+            const float cc = __builtin_fmaf(-surf.obj.w, surf.obj.w, dot(oc, oc));
+            const float disc = __builtin_fmaf(bq, bq, -cc);
+            float t = disc > 0.0f ? sqrt_cr(disc) - bq : 0.0f;
+            if (!(t > 0.0f)) t = 0.0f;
+            const v3 Q = fma3(T, t, P);
+            v3 D = T;
+            if (bend) {  // D = normalize(refract(T, -n2, index)), n2 = outward normal at the exit point
+                const v3 n2 = normalize(fma3(T, t, oc));
+                const float ce = dot(n2, T);
+                const float k2 = __builtin_fmaf(-(idx * idx), __builtin_fmaf(-ce, ce, 1.0f), 1.0f);
+                if (k2 < 0.0f) break;  // total internal reflection
+                const float s2 = __builtin_fmaf(-idx, ce, sqrt_cr(k2));
+                D = normalize(mk(__builtin_fmaf(s2, n2.x, idx * T.x), __builtin_fmaf(s2, n2.y, idx * T.y), __builtin_fmaf(s2, n2.z, idx * T.z)));
+            }
+            n_trans++;
+            const float len = 1.0f + trace_cone<N, 3, REP>(S.sphere, Q + D, D, p.ray_radius, p.render_dist, p.max_steps, rep);
+            if (!(len < p.render_dist)) break;
+            const v3 hit = fma3(D, fmax_(len, 0.0f), Q);
+            float rr, rg, rb;
+            shade_point<N, REP>(S, p, hit, Q, D, rr, rg, rb, surf);
+            n_points++;
+            r = __builtin_fmaf(weight, rr, r);
+            g = __builtin_fmaf(weight, rg, g);
+            b = __builtin_fmaf(weight, rb, b);
+            P = hit;
+            I = D;
         }
     }
     return true;
@@ -342,11 +399,11 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
         b = dst[idx * 3 + 2];
         have_sum = true;
     }
-    uint32_t n_hits = 0, n_points = 0, n_refl = 0;
+    uint32_t n_hits = 0, n_points = 0, n_refl = 0, n_trans = 0;
     for (uint32_t sb = 0; sb < p.n_batch; sb++) {
         float jx, jy, sr, sg, sbl;
         sample_jitter(p.sample0 + sb, p.n_strata, p.width, p.height, &jx, &jy);
-        const bool hit = inside && shade_pixel<N, REP, REFL>(S, p, jx, jy, px, py, depth[(size_t)sb * p.depth_stride + (size_t)py * p.depth_w + px], sr, sg, sbl, n_points, n_refl);  // :135
+        const bool hit = inside && shade_pixel<N, REP, REFL>(S, p, jx, jy, px, py, depth[(size_t)sb * p.depth_stride + (size_t)py * p.depth_w + px], sr, sg, sbl, n_points, n_refl, n_trans);  // :135
         if (have_sum) {
             r += sr;
             g += sg;
@@ -362,15 +419,17 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
     // hit-pixel statistics: one atomic per wave, spread over 1024 slots (a single hot word serves only
     // ~90 atomics/us chip-wide and made this kernel atomic-bound); the host sums the slots
     if (lane == 0 && n_hits) atomicAdd((unsigned long long*)&counters[blockIdx.x & 1023u], (unsigned long long)n_hits);
-    if (REFL) {  // reflection hits shaded / mirror rays marched: slots 1024.. and 2048..
-        unsigned long long pts = n_points, rays = n_refl;
+    if (REFL) {  // secondary hits shaded / mirror rays marched / transmitted rays marched: slots 1024.., 2048.. and 3072..
+        unsigned long long pts = n_points, rays = n_refl, trs = n_trans;
         for (int off = 32; off > 0; off >>= 1) {
             pts += __shfl_down(pts, off);
             rays += __shfl_down(rays, off);
+            trs += __shfl_down(trs, off);
         }
-        if (lane == 0 && rays) {
+        if (lane == 0 && (rays | trs)) {
             atomicAdd((unsigned long long*)&counters[1024u + (blockIdx.x & 1023u)], pts);
             atomicAdd((unsigned long long*)&counters[2048u + (blockIdx.x & 1023u)], rays);
+            atomicAdd((unsigned long long*)&counters[3072u + (blockIdx.x & 1023u)], trs);
         }
     }
 
@@ -524,8 +583,8 @@ template <int N>
 static void shade_launch_n(hipStream_t st, dim3 grid, const ShadeSet& S, const ShadeParams& p, const float* depth, float* dst,
                            uint64_t* counters) {
     const bool rep = p.repeat[0] > 0.0f || p.repeat[1] > 0.0f || p.repeat[2] > 0.0f;
-    // the reference as shipped (no reflections, no repetition) first; the sketched variants behind it
-    if (p.reflections == 0) {
+    // the reference as shipped (no reflections, no transmission, no repetition) first; the sketched variants behind it
+    if (p.reflections == 0 && p.transmissions == 0) {
         if (rep) hipLaunchKernelGGL((shade_kernel<N, true, false>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
         else hipLaunchKernelGGL((shade_kernel<N, false, false>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
     } else {

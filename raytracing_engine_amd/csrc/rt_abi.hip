@@ -68,6 +68,7 @@ void fill_shade_set(const rt_mutable_data& s, rt::ShadeSet* out) {
         out->mat_color_ambient[i] = make_float4(s.mats[i].color[0], s.mats[i].color[1], s.mats[i].color[2], s.mats[i].ambient);
         out->mat_shine[i] = s.mats[i].shine;
         out->mat_specular[i] = s.mats[i].specular;
+        out->mat_diffuse[i] = s.mats[i].diffuse;
     }
     for (uint32_t i = 0; i < RT_MAX_LIGHTS; i++) {
         out->light_pos[i] = make_float4(s.lights[i].pos[0], s.lights[i].pos[1], s.lights[i].pos[2], 0.0f);
@@ -206,6 +207,9 @@ int enqueue_samples(Ctx* c, const float rot[4], const float pos[3], uint32_t s0,
     std::memcpy(sp.repeat, c->cfg.repeat, sizeof sp.repeat);
     sp.reflections = c->cfg.reflections;
     sp.reflectivity = c->cfg.reflectivity;
+    sp.transmissions = c->cfg.transmissions;
+    sp.transparency = c->cfg.transparency;
+    sp.refraction_index = c->cfg.refraction_index;
     int rc;
     {
         rt::RoctxRange rr("rt.path_a.shade");
@@ -227,7 +231,7 @@ int render_common(Ctx* c, const float rot[4], const float pos[3], uint32_t spp, 
     if (int rc = bind(c)) return rc;
 
     const bool stage_events = c->cfg.profile_stages != 0;
-    RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 3 * 1024 * sizeof(uint64_t), c->stream));
+    RT_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * 1024 * sizeof(uint64_t), c->stream));
     RT_HIP(c, hipEventRecord(c->ev_begin, c->stream));
     const uint32_t batch = c->cfg.fuse_levels ? 1u : std::min(spp, kSampleBatch);
     if (int rc = ensure_levels(c, batch)) return rc;
@@ -247,9 +251,9 @@ int render_common(Ctx* c, const float rot[4], const float pos[3], uint32_t spp, 
     c->stats.cone_threads = cone_threads * spp;  // upper bound when partitioned
     if (sync) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
-        uint64_t slots[3 * 1024], counters[3] = {0, 0, 0};  // hit pixels, reflection hits shaded, mirror rays
+        uint64_t slots[4 * 1024], counters[4] = {0, 0, 0, 0};  // hit pixels, secondary hits shaded, mirror rays, transmitted rays
         RT_HIP(c, hipMemcpy(slots, c->d_counters, sizeof slots, hipMemcpyDeviceToHost));
-        for (int k = 0; k < 3 * 1024; k++) counters[k >> 10] += slots[k];
+        for (int k = 0; k < 4 * 1024; k++) counters[k >> 10] += slots[k];
         uint64_t owned_px = 0;
         {  // pixels inside the frame that belong to this rank's tiles
             const rt::Partition& pt = c->part;
@@ -263,6 +267,7 @@ int render_common(Ctx* c, const float rot[4], const float pos[3], uint32_t spp, 
         c->stats.hit_pixels = counters[0];
         c->stats.shadow_rays = (counters[0] + counters[1]) * c->scene.lightCount;  // one shadowRay per light per shaded surface point
         c->stats.reflection_rays = counters[2];
+        c->stats.transmission_rays = counters[3];
         RT_HIP(c, hipEventElapsedTime(&c->stats.ms_total, c->ev_begin, c->ev_end));
         c->stats.ms_cone = c->stats.ms_shade = 0.0f;
         std::memset(c->stats.ms_level, 0, sizeof c->stats.ms_level);
@@ -312,6 +317,9 @@ int rt_default_config(rt_config* cfg) {
     cfg->repeat[0] = cfg->repeat[1] = cfg->repeat[2] = 0.0f;
     cfg->reflections = 0;  // the reference has none (fragment.glsl:125 is a TODO)
     cfg->reflectivity = 0.5f;
+    cfg->transmissions = 0;  // the reference has none (fragment.glsl:124,126 are TODOs)
+    cfg->transparency = 0.5f;
+    cfg->refraction_index = 1.0f;
     return RT_OK;
 }
 
@@ -362,7 +370,7 @@ int rt_create(rt_ctx** out, int device_ordinal) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_end);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 3 * 1024 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_counters, 4 * 1024 * sizeof(uint64_t));
     for (uint32_t i = 0; e == hipSuccess && i < RT_MAX_LEVELS + 2; i++) {
         hipEvent_t ev;
         e = hipEventCreate(&ev);
@@ -415,6 +423,9 @@ int rt_set_config(rt_ctx* ctx, const rt_config* cfg) {
         if (!(r >= 0.0f) || !(r < 3.0e38f)) return c->fail(RT_ERR_INVALID, "repeat periods must be finite and >= 0");
     if (variant && cfg->fuse_levels) return c->fail(RT_ERR_INVALID, "march_algorithm / repeat need fuse_levels = 0");
     if (cfg->reflections > 8u || !(cfg->reflectivity >= 0.0f) || !(cfg->reflectivity <= 1.0f)) return c->fail(RT_ERR_INVALID, "reflections %u (0..8) / reflectivity %g (0..1)", cfg->reflections, (double)cfg->reflectivity);
+    if (cfg->transmissions > 8u || !(cfg->transparency >= 0.0f) || !(cfg->transparency <= 1.0f) || !(cfg->refraction_index >= 1.0f) || !(cfg->refraction_index <= 4.0f))
+        return c->fail(RT_ERR_INVALID, "transmissions %u (0..8) / transparency %g (0..1) / refraction_index %g (1..4)", cfg->transmissions, (double)cfg->transparency,
+                       (double)cfg->refraction_index);
     c->cfg = *cfg;
     c->state_version++;
     return RT_OK;

@@ -33,6 +33,7 @@ struct ShadeSet {  // everything fragment.glsl reads from MutableData
     float4 mat_color_ambient[RT_MAX_MATERIALS];  // rgb, ambient
     float mat_shine[RT_MAX_MATERIALS];
     float mat_specular[RT_MAX_MATERIALS];  // read only by the mirror-reflection variant (the reference never reads mat.specular)
+    float mat_diffuse[RT_MAX_MATERIALS];   // read only by the transmission variant (the reference never reads mat.diffuse)
     float4 light_pos[RT_MAX_LIGHTS];
     float4 light_color[RT_MAX_LIGHTS];
     uint32_t light_count;
@@ -89,6 +90,8 @@ struct ShadeParams {
     float repeat[3];  // > 0: domain repetition period on that axis (utilities.glsl:31-34)
     uint32_t reflections;  // mirror bounces (0 = the reference as shipped)
     float reflectivity;
+    uint32_t transmissions;  // spheres a transmitted ray may cross (0 = the reference as shipped)
+    float transparency, refraction_index;
 };
 
 // Sub-pixel offset of sample s of an n x n stratified pixel in NDC: the stratum centre (i + 0.5)/n inside
@@ -229,7 +232,7 @@ struct Ctx {
     uint32_t last_image = 0;             // image of the batch that holds the last sample rendered
     float* d_rgb = nullptr;         // full frame, f32 x 3
     uint8_t* d_rgba8 = nullptr;     // rt_read_rgba8 staging, width*height*4, allocated on first use, freed with the frame
-    uint64_t* d_counters = nullptr;  // 3 x 1024 slots: hit pixels, reflection hits shaded, mirror rays; summed on the host
+    uint64_t* d_counters = nullptr;  // 4 x 1024 slots: hit pixels, secondary hits shaded, mirror rays, transmitted rays; summed on the host
     Partition part{0, 1, 0, 0};
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;

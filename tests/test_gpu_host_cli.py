@@ -84,6 +84,11 @@ def test_sketched_variants_and_frames_in_flight(exe, tmp_path):
     cfg = O.default_config()
     cfg.reflections, cfg.reflectivity = 2, 0.75
     assert np.abs(read_pfm(out) - O.render_a(O.default_scene(), 160, 96, cfg=cfg)["rgb"]).max() <= 1e-4
+    for flag, (n, transparency, index) in (("2,0.75", (2, 0.75, 1.0)), ("2,0.75,1.5", (2, 0.75, 1.5))):  # fragment.glsl:124 "TODO: transparency", :126 "TODO: refraction"
+        subprocess.run([exe, "--size", "160x96", "--transmit", flag, "--out", str(out)], check=True)
+        cfg = O.default_config()
+        cfg.transmissions, cfg.transparency, cfg.refraction_index = n, transparency, index
+        assert np.abs(read_pfm(out) - O.render_a(O.default_scene(), 160, 96, cfg=cfg)["rgb"]).max() <= 1e-4
     a, b = tmp_path / "sync.ppm", tmp_path / "slots.ppm"
     subprocess.run([exe, "--size", "160x96", "--frames", "5", "--out", str(a)], check=True)
     res = subprocess.run([exe, "--size", "160x96", "--frames", "5", "--inflight", "3", "--out", str(b)], check=True, capture_output=True, text=True)

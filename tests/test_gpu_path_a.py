@@ -81,7 +81,8 @@ def test_camera_poses(renderer, yaw, pitch, pos):
 
 
 @pytest.mark.parametrize("name", ["path_a_default_64.npz", "path_a_default_turn_96x64.npz", "path_a_cornell_256.npz",
-                                  "path_a_alg1_96x64.npz", "path_a_alg2_96x64.npz", "path_a_repeat_96x64.npz", "path_a_mirror_96x64.npz"])
+                                  "path_a_alg1_96x64.npz", "path_a_alg2_96x64.npz", "path_a_repeat_96x64.npz", "path_a_mirror_96x64.npz",
+                                  "path_a_transparency_96x64.npz", "path_a_refraction_96x64.npz"])
 def test_against_committed_fixture(renderer, golden_dir, name):
     g = np.load(os.path.join(golden_dir, name))
     renderer.set_scene(g["scene"].tobytes())
@@ -97,10 +98,13 @@ def test_against_committed_fixture(renderer, golden_dir, name):
             cfg.repeat[:] = [float(v) for v in g["repeat"]]
             cfg.max_steps = int(g["max_steps"])
             cfg.reflections, cfg.reflectivity = int(g["reflections"]), float(g["reflectivity"])
+            if "transmissions" in g:
+                cfg.transmissions, cfg.transparency, cfg.refraction_index = int(g["transmissions"]), float(g["transparency"]), float(g["refraction_index"])
             renderer.set_config(cfg)
             rgb = renderer.render(g["rot"], g["pos"])
             st = renderer.stats()
             assert [st["hit_pixels"], st["shadow_rays"], st["reflection_rays"]] == [int(g["counters"][3]), int(g["counters"][4]), int(g["counters"][7])]
+            assert st["transmission_rays"] == (int(g["counters"][8]) if len(g["counters"]) > 8 else 0)
             for i in range(count):
                 got, want = renderer.read_level(i), g[f"level{i}"]
                 m = on_screen_mask(want.shape, i, count, w, h) if fused else np.ones(want.shape, bool)
@@ -229,12 +233,61 @@ def test_mirror_reflections(renderer, reflections, reflectivity, n_obj, repeat):
         renderer.set_config(renderer.default_config())
 
 
+@pytest.mark.parametrize("transmissions,transparency,index,reflections", [(1, 0.5, 1.0, 0), (2, 0.8, 1.0, 0), (1, 0.6, 1.5, 0), (3, 1.0, 1.33, 0), (2, 0.7, 1.5, 2)])
+@pytest.mark.parametrize("n_obj", [4, 8])
+@pytest.mark.parametrize("repeat", [(0.0, 0.0, 0.0), (40.0, 0.0, 40.0)])
+def test_transmission(renderer, transmissions, transparency, index, reflections, n_obj, repeat):
+    """SURVEY.md section 8 f.4, the remainder: fragment.glsl:124 "TODO: transparency" and :126 "TODO: refraction" in the reference;
+    the build-defined transmission chain (rt_config.transmissions / transparency / refraction_index; specification in
+    include/rt_abi.h and oracle/oracle.h) against the oracle's restatement: RGB <= 1e-4, hit / shadow-ray / mirror-ray /
+    transmitted-ray counts equal, 1 and 4 spp, with and without repeat(), alone and together with the mirror chain."""
+    scene = R.default_scene() if n_obj == 4 else R.cornell_scene()
+    w, h = 200, 120
+    rot, pos = host.camera_quat(0.3, -0.1), (0.5, -1.0, 0.2)
+    ocfg = O.default_config()
+    ocfg.transmissions, ocfg.transparency, ocfg.refraction_index, ocfg.max_steps = transmissions, transparency, index, 4096
+    ocfg.reflections, ocfg.reflectivity = reflections, 0.6
+    ocfg.repeat[:] = repeat
+    ref = O.render_a(oracle_scene(scene), w, h, rot=rot, pos=pos, cfg=ocfg)
+    plain = O.render_a(oracle_scene(scene), w, h, rot=rot, pos=pos, want_levels=False)
+    assert ref["counters"]["transmission_rays"] >= 0.5 * ref["counters"]["hit_pixels"]
+    # (the start-up scene's four spheres are ball lenses far apart: from this camera the bent rays find nothing behind them and the
+    # frame is the plain one; inside the eight-sphere room they always land on a wall)
+    assert repeat[0] > 0 or (index != 1.0 and n_obj == 4) or np.abs(ref["rgb"] - plain["rgb"]).max() > 1e-3
+    try:
+        cfg = renderer.default_config()
+        cfg.transmissions, cfg.transparency, cfg.refraction_index, cfg.max_steps = transmissions, transparency, index, 4096
+        cfg.reflections, cfg.reflectivity = reflections, 0.6
+        cfg.repeat[:] = repeat
+        renderer.set_config(cfg)
+        renderer.set_scene(scene)
+        renderer.resize(w, h)
+        rgb, depth = renderer.render(rot, pos, want_depth=True)
+        assert np.array_equal(depth, ref["levels"][-1])
+        assert np.abs(rgb - ref["rgb"]).max() <= RGB_TOL
+        st = renderer.stats()
+        assert (st["hit_pixels"], st["shadow_rays"], st["reflection_rays"], st["transmission_rays"]) == \
+            (ref["counters"]["hit_pixels"], ref["counters"]["shadow_rays"], ref["counters"]["reflection_rays"], ref["counters"]["transmission_rays"])
+        rgb4 = renderer.render(rot, pos, spp=4)
+        acc = None
+        for s in range(4):
+            i, j = s % 2, s // 2
+            jit = (((np.float32(2 * i + 1) / np.float32(2)) - np.float32(1)) / np.float32(w),
+                   ((np.float32(2 * j + 1) / np.float32(2)) - np.float32(1)) / np.float32(h))
+            f = O.render_a(oracle_scene(scene), w, h, rot=rot, pos=pos, jitter=jit, cfg=ocfg, want_levels=False)["rgb"]
+            acc = f if acc is None else acc + f
+        assert np.abs(rgb4 - acc / np.float32(4)).max() <= RGB_TOL
+    finally:
+        renderer.set_config(renderer.default_config())
+
+
 def test_sketched_variants_error_behaviour(renderer):
     cfg = renderer.default_config()
     cfg.march_algorithm = 4
     with pytest.raises(R.RtError):
         renderer.set_config(cfg)
-    for bad in (dict(reflections=9), dict(reflectivity=1.5), dict(reflectivity=-0.1)):
+    for bad in (dict(reflections=9), dict(reflectivity=1.5), dict(reflectivity=-0.1), dict(transmissions=9), dict(transparency=1.5), dict(transparency=-0.1),
+                dict(refraction_index=0.9), dict(refraction_index=float("nan")), dict(refraction_index=5.0)):
         cfg = renderer.default_config()
         for k, v in bad.items():
             setattr(cfg, k, v)

@@ -225,7 +225,8 @@ def test_unorm8():
 
 
 FIXTURES_A = ["path_a_default_64.npz", "path_a_default_turn_96x64.npz", "path_a_cornell_256.npz",
-              "path_a_alg1_96x64.npz", "path_a_alg2_96x64.npz", "path_a_repeat_96x64.npz", "path_a_mirror_96x64.npz"]
+              "path_a_alg1_96x64.npz", "path_a_alg2_96x64.npz", "path_a_repeat_96x64.npz", "path_a_mirror_96x64.npz",
+              "path_a_transparency_96x64.npz", "path_a_refraction_96x64.npz"]
 
 
 def fixture_config(g):
@@ -235,6 +236,8 @@ def fixture_config(g):
     cfg.max_steps = int(g["max_steps"])
     if "reflections" in g:  # fixtures older than the mirror variant do not carry the fields
         cfg.reflections, cfg.reflectivity = int(g["reflections"]), float(g["reflectivity"])
+    if "transmissions" in g:
+        cfg.transmissions, cfg.transparency, cfg.refraction_index = int(g["transmissions"]), float(g["transparency"]), float(g["refraction_index"])
     return cfg
 
 
@@ -351,3 +354,64 @@ def test_mirror_reflection_known_answers():
     two = O.render_a(scene(1.0), w, h, cfg=cfg, want_levels=False)
     assert (two["rgb"] >= one["rgb"]).all() and two["counters"]["reflection_rays"] > one["counters"]["reflection_rays"]
     assert np.isfinite(two["rgb"]).all()
+
+
+# ---- transmission (fragment.glsl:124 "TODO: transparency", :126 "TODO: refraction"; build-defined, oracle.h) ---------
+def test_transmission_known_answers():
+    """A clear sphere in front of a lit red one: a transmitted ray per hit pixel, light is only ever added and what shows through
+    the clear sphere is the red one; transparency 0 or mat.diffuse 0 is the reference image; the added light is linear in the
+    weight; at normal incidence Snell's law does not bend the ray, so the pixel that looks through the pole is the same with
+    index 1 and 1.5 while the others move; a second pass crosses the red sphere too and finds nothing behind it."""
+    def scene(diffuse):
+        sc = O.Scene()
+        sc.matCount = sc.objCount = 2
+        sc.lightCount = 1
+        for i, (pos, size, col) in enumerate([((0, 10, 0), 3.0, (0.9, 0.9, 0.9)), ((0, 24, 0), 5.0, (1.0, 0.2, 0.2))]):
+            sc.objs[i].pos[:] = pos
+            sc.objs[i].size = size
+            sc.mats[i].color[:] = col
+            sc.mats[i].diffuse = diffuse
+            sc.mats[i].specular = 1.0
+            sc.mats[i].shine = 4.0
+            sc.mats[i].ambient = 0.05
+        sc.lights[0].pos[:] = (0, 14, 14)
+        sc.lights[0].color[:] = (2, 2, 2)
+        return sc
+
+    w, h = 97, 97  # odd: pixel (48, 48) looks exactly along the view axis, through the clear sphere's pole
+    base = O.render_a(scene(1.0), w, h, want_levels=False)
+    cfg = O.default_config()
+    assert cfg.transmissions == 0 and cfg.transparency == 0.5 and cfg.refraction_index == 1.0
+    cfg.transmissions = 1
+    one = O.render_a(scene(1.0), w, h, cfg=cfg, want_levels=False)
+    d = one["rgb"] - base["rgb"]
+    assert one["counters"]["transmission_rays"] == base["counters"]["hit_pixels"] and base["counters"]["transmission_rays"] == 0
+    assert one["counters"]["reflection_rays"] == 0
+    changed = np.abs(d).max(-1) > 0
+    assert d.min() >= 0 and changed.sum() > 100
+    on_clear = changed & (np.abs(base["rgb"][..., 0] - base["rgb"][..., 1]) <= 1e-6 * (1 + base["rgb"][..., 0]))  # primary hit = the grey, clear sphere
+    assert on_clear.sum() > 50 and d[on_clear][:, 0].sum() > 4 * d[on_clear][:, 1].sum()  # what shows through it is the red sphere
+    # one shadow ray per light for every shaded point: the primary hits and the points found behind the clear sphere
+    assert one["counters"]["shadow_rays"] > base["counters"]["shadow_rays"]
+    cfg.transparency = 0.0
+    assert np.array_equal(O.render_a(scene(1.0), w, h, cfg=cfg, want_levels=False)["rgb"], base["rgb"])
+    cfg.transparency = 0.5
+    assert np.array_equal(O.render_a(scene(0.0), w, h, cfg=cfg, want_levels=False)["rgb"], O.render_a(scene(0.0), w, h, want_levels=False)["rgb"])
+    cfg.transparency = 0.25  # linear in the weight (one pass, exact powers of two)
+    q = O.render_a(scene(1.0), w, h, cfg=cfg, want_levels=False)["rgb"] - base["rgb"]
+    np.testing.assert_allclose(q, d * np.float32(0.5), rtol=0, atol=2e-7)
+    cfg.transparency = 0.5
+    cfg.refraction_index = 1.5
+    bent = O.render_a(scene(1.0), w, h, cfg=cfg, want_levels=False)
+    # a sphere entered from outside never reflects totally; the rays that end are the silhouette pixels, where only the CONE touched
+    # the sphere (disc <= 0: no crossing, the bent ray points inward at its "exit")
+    assert 0.7 * one["counters"]["transmission_rays"] <= bent["counters"]["transmission_rays"] <= one["counters"]["transmission_rays"]
+    # the axis pixel enters and leaves at normal incidence: Snell's law does not bend it (its neighbours already move: a ball lens)
+    np.testing.assert_allclose(bent["rgb"][48, 48], one["rgb"][48, 48], rtol=0, atol=1e-6)
+    assert one["rgb"][48, 48, 0] > base["rgb"][48, 48, 0]
+    moved = np.abs(bent["rgb"] - one["rgb"]).max(-1) > 1e-3
+    assert moved.sum() > 100 and np.isfinite(bent["rgb"]).all() and (bent["rgb"] >= base["rgb"]).all()
+    cfg.refraction_index = 1.0
+    cfg.transmissions = 2
+    two = O.render_a(scene(1.0), w, h, cfg=cfg, want_levels=False)
+    assert two["counters"]["transmission_rays"] > one["counters"]["transmission_rays"] and np.array_equal(two["rgb"], one["rgb"])  # nothing behind the red sphere
