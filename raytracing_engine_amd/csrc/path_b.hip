@@ -135,12 +135,18 @@ struct Group {
 __device__ __forceinline__ bool has_nodes(const Group& g) { return g.y > 0x00ffffffu; }
 __device__ __forceinline__ bool has_tris(const Group& t) { return (t.y & 0xffu) != 0u; }
 
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
 // Per-lane traversal stack of 8-byte groups.  The first `lds_cap` entries live in LDS (column of
 // this thread, stride 256 entries: conflict-free); the tree pushes at most one pending sibling
 // group per level, the builder reports the depth and the host sizes lds_cap + spill_cap to it;
 // entries beyond lds_cap spill to a global column (entry-major, coalesced across a wave).
 struct TravStack {
-    unsigned long long* lds;
+    // The LDS part is an address-space-qualified pointer on purpose: with two generic pointers the compiler folds pop()'s two
+    // loads into ONE flat_load on a selected address - the flat path, both address computations and a vmcnt(0) + lgkmcnt(0) wait
+    // for every pop, even when nothing ever spills.
+    lds_u64* lds;
     unsigned long long* spill;
     size_t spill_stride;
     int lds_cap, spill_cap;
@@ -157,7 +163,9 @@ struct TravStack {
     }
     __device__ __forceinline__ Group pop() {  // caller checks sp > 0
         --sp;
-        const unsigned long long v = sp < lds_cap ? lds[sp * 256] : spill[(size_t)(sp - lds_cap) * spill_stride];
+        unsigned long long v;
+        if (sp < lds_cap) v = lds[sp * 256];
+        else v = spill[(size_t)(sp - lds_cap) * spill_stride];
         return Group{(uint32_t)v, (uint32_t)(v >> 32)};
     }
 };
@@ -428,8 +436,6 @@ constexpr uint32_t kPoolRing = 128;  // groups; a flush is due at <= 64, a round
 // The pool is read and written by different lanes of ONE wave: DS operations of a wave execute in program order, so no
 // barrier instruction is needed; pool_sync() only keeps the COMPILER from moving LDS accesses across the phase boundaries
 // (the pointers are not volatile: volatile accesses would stay on generic pointers and become flat_* instructions).
-typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct TriPool {
     lds_u64* ring;  // kPoolRing groups: x = tri_base, y = hit slots 7..0 | leafmask 15..8 | owner lane 21..16
     lds_u64* best;  // 64 owners: closest = (t bits << 32) | triangle id; any-hit: != 0 = occluded
@@ -507,9 +513,10 @@ constexpr int kTrisPerRound = 1;
 // How the triangle tests of the per-lane kernels are scheduled (rt_pt_params.tune_tri_mode):
 //   TRI_INLINE  every round ends with a triangle phase for the lanes that hold a leaf hit (rounds 1 and 2 of the build)
 //   TRI_POOL    wave-pooled tests: leaf hits go to a per-wave LDS ring, the wave tests 64 of them at once (above)
+//   TRI_INLINE_PF  the inline phase with the software-pipelined refill (trace_queue_pf below): rays wait in a per-wave LDS ring
 //   TRI_DEFER   postponed tests: a lane parks up to two leaf-hit groups in registers and keeps visiting nodes; the triangle
 //               phase runs when enough lanes hold a group (or enough of them can do nothing else)
-enum { TRI_INLINE = TRI_MODE_INLINE, TRI_POOL = TRI_MODE_POOL, TRI_DEFER = TRI_MODE_DEFER };
+enum { TRI_INLINE = TRI_MODE_INLINE, TRI_POOL = TRI_MODE_POOL, TRI_DEFER = TRI_MODE_DEFER, TRI_INLINE_PF = TRI_MODE_INLINE_PF };
 
 struct PoolMem {  // LDS of one wave's pool (TRI_POOL kernels only)
     lds_u64* ring;
@@ -525,7 +532,7 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
                                             uint32_t shadow_stat /* word of the shadow-ray node counter: 4 alone, 11 inside the fused launch */ = 4u) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t n = *count_ptr;
+    const uint32_t n = uniform(*count_ptr);
     const int tris_per_round = (int)((refill_min >> 8) & 0xffu) ? (int)((refill_min >> 8) & 0xffu) : kTrisPerRound;
     refill_min &= 0xffu;
     TravCounters tc{0, 0, 0};
@@ -536,7 +543,9 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
     uint32_t slot = 0;  // closest: path id; any-hit: shadow-queue index
     bool has_ray = false, occluded = false;
     bool exhausted = n == 0;  // wave-uniform: every stream of the queue has been found dry
-    uint32_t stream = (blockIdx.x * 4u + (threadIdx.x >> 6)) & (PT_HEADS - 1u);  // wave-uniform: the stream this wave pulls from
+    // (readfirstlane: threadIdx.x >> 6 is wave-uniform, but only this tells the compiler, and everything the stream index touches -
+    // the dry-stream test, `exhausted`, the refill branch - would otherwise live in vector registers under lane masks)
+    uint32_t stream = uniform((blockIdx.x * 4u + (threadIdx.x >> 6)) & (PT_HEADS - 1u));  // wave-uniform: the stream this wave pulls from
     uint32_t dry_streams = 0;                                                    // wave-uniform
     uint32_t rounds = 0, alive_rounds = 0;                // COUNT only
     bool alive = false;       // this lane still has traversal work for its ray
@@ -739,6 +748,191 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
     if (tc.overflow) atomicOr((unsigned int*)&stats[2], 1u);
 }
 
+// ---- software-pipelined refill (TRI_INLINE_PF) ------------------------------------------------------
+// The blocking refill above is three dependent memory round trips (head atomic -> queue entry -> ray) during which the whole
+// wave stands still, plus ~190 vector instructions, and that is why its threshold sits at 24 idle lanes: measured, a refill event
+// costs what 2.2 traversal rounds cost, so on average 16 of a wave's 64 lanes wait for the next one (47.8 alive per round).
+// Here the fetch is taken out of the lanes' way: the wave keeps a ring of kPfRing ready rays in LDS and a four-stage pipeline
+// that advances ONE stage per traversal round - reserve kPfBatch queue entries (returning atomic, result not awaited), read the
+// queue entries, read the rays, park them in the ring - so every load was issued a round earlier and its data has arrived behind
+// the node fetches in between (vector memory returns in order).  A lane that finishes takes the next ray out of LDS as soon as
+// `pop_min` lanes are idle (default 8).  The rays in flight chip-wide grow by at most kPfRing per wave (25 %).
+constexpr uint32_t kPfRing = 16, kPfBatch = 8;
+typedef float f4v __attribute__((ext_vector_type(4)));  // native vector: HIP's float4 class has no address-space-qualified members
+typedef __attribute__((address_space(3))) f4v lds_f4;
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void trace_queue_pf(const PtScene& sc, const PtState& st, const uint32_t* __restrict__ queue,
+                                               const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
+                                               unsigned long long* __restrict__ stats, TravStack& stk, const uint8_t* perm_lut, uint32_t refill_min,
+                                               lds_f4* ring /* 2 x kPfRing: origin as loaded, (direction, slot bits) */, uint32_t shadow_stat = 4u) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t n = uniform(*count_ptr);
+    const int tris_per_round = (int)((refill_min >> 8) & 0xffu) ? (int)((refill_min >> 8) & 0xffu) : kTrisPerRound;
+    const uint32_t pop_min = (refill_min & 0xffu) ? ((refill_min & 0xffu) < 64u ? (refill_min & 0xffu) : 64u) : 8u;
+    TravCounters tc{0, 0, 0};
+
+    TRay r = make_tray(mk(0.0f, 0.0f, 0.0f), mk(0.0f, 1.0f, 0.0f), 0.0f);
+    Hit best{0.0f, -1, 0u};
+    Group G{0u, 0u}, T{0u, 0u};
+    uint32_t slot = 0;  // closest: path id; any-hit: shadow-queue index
+    bool has_ray = false, occluded = false, alive = false;
+    uint32_t rounds = 0, alive_rounds = 0;  // COUNT only
+
+    // fetch pipeline (wave-uniform unless noted)
+    uint32_t stream = uniform((blockIdx.x * 4u + (threadIdx.x >> 6)) & (PT_HEADS - 1u));
+    uint32_t dry_streams = 0;
+    uint32_t fetch_done = n == 0u ? 1u : 0u;  // every stream of the queue has been found dry
+    uint32_t pf_stage = 0;                // 0 idle, 1 entries reserved, 2 queue entries read (closest-hit only), 3 rays read
+    uint32_t pf_base = 0;                 // lane 0: what the head atomic returned
+    uint32_t pf_idx = n, pf_slot = 0;     // per lane < kPfBatch: queue index (>= n: none), path id / shadow index
+    // per lane: the ray, kept as the two 16-byte tuples the loads deliver and the LDS stores take (scalars would be copied out of the
+    // load's registers as soon as it is issued, and the copies wait for the data)
+    f4v pf_o = {0.0f, 0.0f, 0.0f, 0.0f}, pf_d = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t ring_head = 0, ring_count = 0;
+
+    for (;;) {
+        // (the wave-uniform state, pinned to scalar registers: without this the divergence analysis taints it through the lane-
+        // dependent code around it and every branch below becomes a lane-masked region whose merges wait for the loads just issued)
+        pf_stage = uniform(pf_stage);
+        ring_head = uniform(ring_head);
+        ring_count = uniform(ring_count);
+        stream = uniform(stream);
+        dry_streams = uniform(dry_streams);
+        fetch_done = uniform(fetch_done);
+        // ---- one pipeline stage per round; every value used here was requested a round ago ----
+        if (pf_stage == 3u) {
+            const bool valid = pf_idx < n;
+            const unsigned long long vm = __ballot(valid);
+            if (valid) {
+                const uint32_t pos = (ring_head + ring_count + (uint32_t)__popcll(vm & lt_mask)) & (kPfRing - 1u);
+                f4v d4 = pf_d;
+                d4.w = __uint_as_float(pf_slot);
+                ring[2u * pos] = pf_o;
+                ring[2u * pos + 1u] = d4;
+            }
+            ring_count = uniform(ring_count + (uint32_t)__popcll(vm));
+            pf_stage = 0u;
+            pool_sync();
+        } else if (pf_stage == 2u) {
+            // (every lane loads, lanes without an entry a clamped address: a load under a lane predicate is merged into the live
+            // registers with copies, and the copies would wait for the data right here)
+            pf_o = *reinterpret_cast<const f4v*>(&st.ray_o[pf_slot]);
+            pf_d = *reinterpret_cast<const f4v*>(&st.ray_d[pf_slot]);
+            pf_stage = 3u;
+        } else if (pf_stage == 1u) {
+            // Stream-local entry j of stream k is queue entry ((j / 64) * PT_HEADS + k) * 64 + j % 64.
+            const uint32_t base = uniform(pf_base);
+            const uint32_t j = base + lane, je = base + kPfBatch;
+            pf_idx = lane < kPfBatch ? ((((j >> 6) * PT_HEADS + stream) << 6) | (j & 63u)) : n;
+            if (((((je >> 6) * PT_HEADS + stream) << 6) | (je & 63u)) >= n) {  // this stream is dry (entries grow with j): move on
+                stream = (stream + 1u) & (PT_HEADS - 1u);
+                fetch_done = ++dry_streams >= PT_HEADS ? 1u : 0u;
+            }
+            const uint32_t safe = pf_idx < n ? pf_idx : n - 1u;  // n > 0 here
+            if (ANY) {
+                pf_o = *reinterpret_cast<const f4v*>(&st.sh_o[safe]);
+                pf_d = *reinterpret_cast<const f4v*>(&st.sh_d[safe]);
+                pf_slot = safe;
+                pf_stage = 3u;
+            } else {
+                pf_slot = queue[safe];
+                pf_stage = 2u;
+            }
+        }
+        if (pf_stage == 0u && !fetch_done && ring_count + kPfBatch <= kPfRing) {
+            if (lane == 0) pf_base = atomicAdd(head + stream * PT_HEAD_STRIDE, kPfBatch);
+            pf_stage = 1u;
+        }
+
+        // ---- retire finished lanes and hand them rays from the ring ----
+        const unsigned long long idle = __ballot(!alive);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        const bool drained = fetch_done && pf_stage == 0u && ring_count == 0u;
+        if ((ring_count != 0u && n_idle >= pop_min) || (n_idle == 64u && (ring_count != 0u || drained))) {
+            if (!alive && has_ray) {  // retire
+                if (ANY) {
+                    if (!occluded) {
+                        const uint32_t pid = __float_as_uint(st.sh_o[slot].w);
+                        const float4 c = st.sh_c[slot];
+                        float4 L = st.rad[pid];
+                        L.x += c.x;
+                        L.y += c.y;
+                        L.z += c.z;
+                        st.rad[pid] = L;
+                    }
+                } else {
+                    st.hit[slot] = make_float2(best.t, __int_as_float(best.li));
+                }
+                has_ray = false;
+            }
+            const uint32_t m = n_idle < ring_count ? n_idle : ring_count;
+            const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+            if (!alive && rank < m) {
+                const uint32_t pos = (ring_head + rank) & (kPfRing - 1u);
+                const f4v ro = ring[2u * pos], rd = ring[2u * pos + 1u];
+                slot = __float_as_uint(rd.w);
+                if (ANY) {
+                    r = make_tray(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), kShadowTmax);
+                    occluded = false;
+                } else {
+                    r = make_tray(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), __builtin_inff());
+                    best = Hit{__builtin_inff(), -1, 0xffffffffu};
+                }
+                has_ray = true;
+                alive = true;
+                G = root_group();
+                T = Group{0u, 0u};
+                stk.sp = 0;
+            }
+            ring_head = uniform(ring_head + m);
+            ring_count = uniform(ring_count - m);
+            pool_sync();
+            if (m == 0u && drained) break;  // queue and ring empty, every lane retired
+        }
+        if (COUNT) {
+            rounds++;
+            alive_rounds += (uint32_t)__popcll(__ballot(alive));
+        }
+        // node phase: lanes without pending triangles visit their next node
+        if (alive && !has_tris(T)) {
+            if (!has_nodes(G)) {
+                if (stk.sp) G = stk.pop();
+                else alive = false;
+            }
+            if (alive) node_step<COUNT>(sc.nodes, perm_lut, r, G, T, stk, tc);
+        }
+        // triangle phase
+#pragma unroll 1
+        for (int it = 0; it < tris_per_round; it++) {
+            if (alive && has_tris(T)) {
+                if (tri_step<ANY, COUNT>(sc.tris, r, best, T, tc)) {
+                    occluded = true;
+                    alive = false;
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        unsigned long long a = tc.nodes, b = tc.tris;
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
+        }
+        if (lane == 0) {
+            if (!ANY) {
+                atomicAdd(&stats[6], (unsigned long long)rounds);
+                atomicAdd(&stats[7], (unsigned long long)alive_rounds);
+            }
+            atomicAdd(&stats[14], (unsigned long long)rounds);
+            atomicAdd(&stats[ANY ? shadow_stat : 0u], a);
+            atomicAdd(&stats[ANY ? shadow_stat + 1u : 1u], b);
+        }
+    }
+    if (tc.overflow) atomicOr((unsigned int*)&stats[2], 1u);
+}
+
 // LDS of a 256-thread workgroup of the per-lane kernels: the traversal stacks (dynamic), the octant table and, for TRI_POOL
 // kernels, four pools of 1.75 KiB.
 template <int MODE>
@@ -754,11 +948,19 @@ struct PoolLds<TRI_POOL> {
         return PoolMem{(lds_u64*)ring[wave], (lds_u64*)best[wave], (lds_u32*)li[wave]};
     }
 };
+template <>
+struct PoolLds<TRI_INLINE_PF> {
+    f4v rays[4][2 * kPfRing];
+    __device__ __forceinline__ PoolMem get(uint32_t) { return PoolMem{nullptr, nullptr, nullptr}; }
+    __device__ __forceinline__ lds_f4* ring(uint32_t wave) { return (lds_f4*)rays[wave]; }
+};
 constexpr uint32_t kPoolLdsBytes = 4u * (kPoolRing * 8u + 64u * 8u + 64u * 4u);
+constexpr uint32_t kPfLdsBytes = 4u * 2u * kPfRing * 16u;
+constexpr int kPfWaves = 6;    // TRI_INLINE_PF: the prefetch registers (two 16-byte tuples, index, slot) do not fit 72 VGPRs without spills in the loop
 constexpr int kPoolWaves = 7;  // waves per SIMD the TRI_POOL / TRI_DEFER kernels are compiled for (72 VGPRs; the default stack split leaves room for seven workgroups per CU anyway)
 
 template <bool ANY, bool COUNT, int MODE>
-__global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : kPoolWaves) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : MODE == TRI_INLINE_PF ? kPfWaves : kPoolWaves) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
                                                 const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
                                                 unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min, uint32_t tri_cfg) {
     extern __shared__ unsigned long long lds_stack[];  // sk.lds_cap x 256 entries
@@ -766,8 +968,9 @@ __global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : kPoolWaves) void pt_t
     __shared__ PoolLds<MODE> pool;
     build_perm_lut(perm_lut);
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
-    TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
-    trace_queue<ANY, COUNT, MODE>(sc, st, queue, count_ptr, head, stats, stk, perm_lut, refill_min, pool.get(threadIdx.x >> 6), tri_cfg);
+    TravStack stk{(lds_u64*)&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
+    if constexpr (MODE == TRI_INLINE_PF) trace_queue_pf<ANY, COUNT>(sc, st, queue, count_ptr, head, stats, stk, perm_lut, refill_min, pool.ring(threadIdx.x >> 6));
+    else trace_queue<ANY, COUNT, MODE>(sc, st, queue, count_ptr, head, stats, stk, perm_lut, refill_min, pool.get(threadIdx.x >> 6), tri_cfg);
 }
 
 // closest-hit rays of depth d + 1 and the shadow rays of depth d in ONE persistent launch: the two are independent (the
@@ -775,7 +978,7 @@ __global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : kPoolWaves) void pt_t
 // closest-hit queue - the frame's critical path: shade(d + 1) waits for it - and moves on to the shadow queue when that one
 // is dry, instead of leaving the machine to the few long rays of a launch's tail.  One tail per bounce instead of two.
 template <bool COUNT, int MODE>
-__global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : kPoolWaves) void pt_trace_fused(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : MODE == TRI_INLINE_PF ? kPfWaves : kPoolWaves) void pt_trace_fused(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
                                                       const uint32_t* __restrict__ closest_count, uint32_t* __restrict__ closest_head,
                                                       const uint32_t* __restrict__ shadow_count, uint32_t* __restrict__ shadow_head,
                                                       unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min, uint32_t tri_cfg) {
@@ -784,10 +987,15 @@ __global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : kPoolWaves) void pt_t
     __shared__ PoolLds<MODE> pool;
     build_perm_lut(perm_lut);
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
-    TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
-    const PoolMem pm = pool.get(threadIdx.x >> 6);
-    trace_queue<false, COUNT, MODE>(sc, st, queue, closest_count, closest_head, stats, stk, perm_lut, refill_min, pm, tri_cfg);
-    trace_queue<true, COUNT, MODE>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, perm_lut, refill_min, pm, tri_cfg, 11u);
+    TravStack stk{(lds_u64*)&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
+    if constexpr (MODE == TRI_INLINE_PF) {
+        trace_queue_pf<false, COUNT>(sc, st, queue, closest_count, closest_head, stats, stk, perm_lut, refill_min, pool.ring(threadIdx.x >> 6));
+        trace_queue_pf<true, COUNT>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, perm_lut, refill_min, pool.ring(threadIdx.x >> 6), 11u);
+    } else {
+        const PoolMem pm = pool.get(threadIdx.x >> 6);
+        trace_queue<false, COUNT, MODE>(sc, st, queue, closest_count, closest_head, stats, stk, perm_lut, refill_min, pm, tri_cfg);
+        trace_queue<true, COUNT, MODE>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, perm_lut, refill_min, pm, tri_cfg, 11u);
+    }
 }
 
 // ---- packet trace (camera rays) ---------------------------------------------------------------------
@@ -1101,7 +1309,7 @@ __global__ __launch_bounds__(256) void pt_trace_rays(const PtScene sc, const flo
     build_perm_lut(perm_lut);
     // grid-stride so the spill columns (one per launched thread) stay within sk.spill_stride
     const size_t gtid = (size_t)blockIdx.x * 256u + threadIdx.x;
-    TravStack stk{&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
+    TravStack stk{(lds_u64*)&lds_stack[threadIdx.x], sk.spill + gtid, sk.spill_stride, sk.lds_cap, sk.spill_cap, 0};
     for (uint32_t i = (uint32_t)gtid; i < n; i += gridDim.x * 256u) {
         TravCounters tc{0, 0, 0};
         trace_one_ray<COUNT>(sc, origins, dirs, i, any_hit, t_out, tri_out, stk, perm_lut, tc);
@@ -1132,6 +1340,7 @@ int launch_pt_trace(Ctx* c, const PtScene& sc, const PtState& st, const uint32_t
     do {                                                         \
         if (tri_mode == TRI_POOL) RT_LAUNCH_TRACE(ANY, COUNT, TRI_POOL); \
         else if (tri_mode == TRI_DEFER) RT_LAUNCH_TRACE(ANY, COUNT, TRI_DEFER); \
+        else if (tri_mode == TRI_INLINE_PF) RT_LAUNCH_TRACE(ANY, COUNT, TRI_INLINE_PF); \
         else RT_LAUNCH_TRACE(ANY, COUNT, TRI_INLINE);            \
     } while (0)
     if (any_hit) {
@@ -1162,6 +1371,9 @@ int launch_pt_trace_fused(Ctx* c, const PtScene& sc, const PtState& st, const ui
     } else if (tri_mode == TRI_DEFER) {
         if (count) RT_LAUNCH_FUSED(true, TRI_DEFER);
         else RT_LAUNCH_FUSED(false, TRI_DEFER);
+    } else if (tri_mode == TRI_INLINE_PF) {
+        if (count) RT_LAUNCH_FUSED(true, TRI_INLINE_PF);
+        else RT_LAUNCH_FUSED(false, TRI_INLINE_PF);
     } else {
         if (count) RT_LAUNCH_FUSED(true, TRI_INLINE);
         else RT_LAUNCH_FUSED(false, TRI_INLINE);
@@ -1171,7 +1383,7 @@ int launch_pt_trace_fused(Ctx* c, const PtScene& sc, const PtState& st, const ui
     return RT_OK;
 }
 
-uint32_t pt_pool_lds_bytes(uint32_t tri_mode) { return tri_mode == TRI_POOL ? kPoolLdsBytes : 0u; }
+uint32_t pt_pool_lds_bytes(uint32_t tri_mode) { return tri_mode == TRI_POOL ? kPoolLdsBytes : tri_mode == TRI_INLINE_PF ? kPfLdsBytes : 0u; }
 
 int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count) {
     const dim3 g((f.n_paths + 255u) / 256u), b(256);

@@ -218,11 +218,12 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
     uint32_t grid_persistent = 0;
     // triangle-test schedule of the per-lane kernels: byte 0 = mode (0 = default), bytes 1-2 = the pool's flush parameters
     const uint32_t tri_mode = (prm->tune_tri_mode & 0xffu) ? (prm->tune_tri_mode & 0xffu) : kDefaultTriMode;
-    if (tri_mode < rt::TRI_MODE_INLINE || tri_mode > rt::TRI_MODE_DEFER) return c->fail(RT_ERR_INVALID, "tune_tri_mode %u (0 .. 3)", tri_mode);
+    if (tri_mode < rt::TRI_MODE_INLINE || tri_mode > rt::TRI_MODE_INLINE_PF) return c->fail(RT_ERR_INVALID, "tune_tri_mode %u (0 .. 4)", tri_mode);
     const uint32_t tri_cfg = prm->tune_tri_mode >> 8;
+    // low byte: idle lanes that trigger a refill (24; 8 with the software-pipelined refill, whose refill is a read from LDS); next byte (tuning): inner steps per round
+    const uint32_t refill_min = (prm->tune_refill_min & 0xffu ? std::min<uint32_t>(prm->tune_refill_min & 0xffu, 64u) : tri_mode == rt::TRI_MODE_INLINE_PF ? 8u : 24u) |
+                                (prm->tune_refill_min & 0xff00u);
     if (int rc = stack_config(c, prm->tune_lds_stack, prm->tune_blocks_per_cu, n_slots * spp_batch, &stack_cap, &grid_persistent, rt::pt_pool_lds_bytes(tri_mode))) return rc;
-    // low byte: idle lanes that trigger a refill; next byte (tuning): inner steps per round
-    const uint32_t refill_min = (prm->tune_refill_min & 0xffu ? std::min<uint32_t>(prm->tune_refill_min & 0xffu, 64u) : 24u) | (prm->tune_refill_min & 0xff00u);
     const uint32_t grid_stride = (uint32_t)c->n_cus * 2u;  // 1024-thread workgroups, grid-stride
 
     StageTimer tm{c, c->cfg.profile_stages != 0, pt.ev_pool, {}, 0};

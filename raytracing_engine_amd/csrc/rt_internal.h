@@ -143,7 +143,7 @@ struct PtScene {
 };
 
 constexpr uint32_t kPacketStackEntries = 40;  // pt_trace_packet's LDS stack of node groups (path_b.hip)
-enum { TRI_MODE_INLINE = 1, TRI_MODE_POOL = 2, TRI_MODE_DEFER = 3 };  // rt_pt_params.tune_tri_mode, byte 0 (path_b.hip: TRI_INLINE, TRI_POOL)
+enum { TRI_MODE_INLINE = 1, TRI_MODE_POOL = 2, TRI_MODE_DEFER = 3, TRI_MODE_INLINE_PF = 4 };  // rt_pt_params.tune_tri_mode, byte 0 (path_b.hip: TRI_INLINE, TRI_POOL)
 
 struct StackCfg {  // per-lane traversal stack of 8-byte entries: lds_cap in LDS, then spill_cap in global memory
     unsigned long long* spill;  // spill_cap x spill_stride entries, entry-major

@@ -43,7 +43,8 @@ def defer(hold=0, stuck=0):
 if a.variants:
     variants = [dict((k, int(v, 0)) for k, v in (kv.split("=") for kv in item.split(",") if kv)) for item in a.variants.split(";")]
 elif a.quick:
-    variants = [dict(tune_tri_mode=1), dict(tune_tri_mode=pool()), dict(tune_tri_mode=defer()), dict(tune_tri_mode=1)]
+    variants = [dict(tune_tri_mode=1), dict(tune_tri_mode=4), dict(tune_tri_mode=4, tune_refill_min=4), dict(tune_tri_mode=4, tune_refill_min=16), dict(tune_tri_mode=4, tune_lds_stack=10),
+                dict(tune_tri_mode=4, tune_blocks_per_cu=6), dict(tune_tri_mode=4, tune_blocks_per_cu=5), dict(tune_tri_mode=1)]
 else:
     variants = [dict(tune_tri_mode=1)]
     variants += [dict(tune_tri_mode=pool(f, w)) for f in (16, 32, 48) for w in (3, 6)]
