@@ -253,7 +253,9 @@ typedef struct rt_pt_params {
     uint32_t tune_no_packet;     /* tuning: 1 = camera rays go through the per-lane traversal kernel like every other ray
                                     (default 0: wave-uniform packet traversal for camera rays) */
     uint32_t tune_sort_rays;     /* tuning: 1 = bounce and shadow rays are sorted inside each 1024-ray workgroup of the shade stage
-                                    (LDS counting sort on direction octant + origin cell) before they enter the queues */
+                                    (LDS counting sort on direction octant + origin cell) before they enter the queues;
+                                    2 = the same sort on keys that predict work (shadow rays: segment length in quarter-octaves;
+                                    bounce rays: dominant axis and steepness of the direction) */
     uint32_t tune_tri_mode;      /* tuning: how the per-lane traversal kernels schedule their ray/triangle tests.  Byte 0: 0 = default,
                                     1 = inline (every round ends with a triangle phase for the lanes that hold a leaf hit),
                                     2 = wave-pooled (leaf hits go to a per-wave ring in LDS; the whole wave tests 64 of them at once,

@@ -207,17 +207,23 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, cons
     // times the rounding error of these fmas for ray origins within 32 M (render_pt_common checks the camera), so a box
     // that holds the ray's hit - or a (t, id) tie - always passes tn <= tf and tn <= tmax.
     const float tlim = r.tmax;
-    uint32_t h8 = 0;  // bit s: the box in child slot s is hit (empty slots hold inverted boxes)
+    // The eight results are collected as SIGN BITS: miss = (miss << 1) | sign(tf - tn), one v_alignbit_b32 behind one
+    // subtraction per child (instead of compare + select + or), children 7 .. 0 so that slot s ends in bit s.  tf - tn < 0 is
+    // tn > tf except where tf = -0 meets tn = +0 (a box that ends exactly at the ray's origin and holds no hit with t > 0:
+    // missing it is as good as entering it, results do not depend on which boxes are visited); no NaN reaches this point
+    // (finite planes, |inv| <= 1e20, tmax = +inf only as the last argument of a minimum).  Empty slots hold inverted boxes.
+    uint32_t miss = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 7; i >= 0; i--) {
         const int w = i >> 2, bsel = i & 3;
         const float tnx = __builtin_fmaf(ubyte_f32(nx[w], bsel), ax, bx), tfx = __builtin_fmaf(ubyte_f32(fx[w], bsel), ax, bx);
         const float tny = __builtin_fmaf(ubyte_f32(ny[w], bsel), ay, by), tfy = __builtin_fmaf(ubyte_f32(fy[w], bsel), ay, by);
         const float tnz = __builtin_fmaf(ubyte_f32(nz[w], bsel), az, bz), tfz = __builtin_fmaf(ubyte_f32(fz[w], bsel), az, bz);
         const float tn = fmax_(fmax_(tnx, tny), fmax_(tnz, 0.0f));
         const float tf = fmin_(fmin_(tfx, tfy), fmin_(tfz, tlim));
-        if (tn <= tf) h8 |= 1u << i;
+        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);
     }
+    const uint32_t h8 = ~miss & 0xffu;  // bit s: the box in child slot s is hit
     // the hit bits are the work lists: inner children to enter, re-keyed front to back (bit slot -> bit slot ^ oct_inv,
     // one byte from a 2 KiB LDS table), and the leaf slots whose single triangle is to be tested
     const uint32_t leafmask = __float_as_uint(n1.z) & 0xffu;
@@ -341,18 +347,20 @@ __device__ __forceinline__ uint32_t block_append(bool want, uint32_t* counter, u
 // sit next to each other in the queue are picked up by the same wave of pt_trace.
 // Must be called by every thread of the workgroup.  lds: kSortBins + 40 words.
 constexpr uint32_t kSortBins = 512;
+template <uint32_t BINS = kSortBins>
 __device__ __forceinline__ uint32_t block_append_sorted(bool want, uint32_t key, uint32_t* counter, uint32_t* lds) {
-    uint32_t* hist = lds;               // kSortBins
+    static_assert(BINS % 64u == 0u && BINS <= kSortBins, "whole waves of bins");
+    uint32_t* hist = lds;               // BINS
     uint32_t* wsum = lds + kSortBins;   // 16 wave sums of the scan + 1 base
-    for (uint32_t i = threadIdx.x; i < kSortBins; i += blockDim.x) hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < BINS; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     uint32_t rank = 0;
     if (want) rank = atomicAdd(&hist[key], 1u);
     __syncthreads();
-    // exclusive scan of the kSortBins counts by the first kSortBins threads (wave scan + wave sums)
+    // exclusive scan of the BINS counts by the first BINS threads (wave scan + wave sums)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t v = 0, incl = 0;
-    if (threadIdx.x < kSortBins) {
+    if (threadIdx.x < BINS) {
         v = hist[threadIdx.x];
         incl = v;
         for (int off = 1; off < 64; off <<= 1) {
@@ -364,7 +372,7 @@ __device__ __forceinline__ uint32_t block_append_sorted(bool want, uint32_t key,
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = 0;
-        for (uint32_t w = 0; w < kSortBins / 64; w++) {
+        for (uint32_t w = 0; w < BINS / 64u; w++) {
             const uint32_t c = wsum[w];
             wsum[w] = total;
             total += c;
@@ -372,7 +380,7 @@ __device__ __forceinline__ uint32_t block_append_sorted(bool want, uint32_t key,
         wsum[16] = total ? atomicAdd(counter, total) : 0u;
     }
     __syncthreads();
-    if (threadIdx.x < kSortBins) hist[threadIdx.x] = wsum[wave] + incl - v;  // bin start inside the workgroup's range
+    if (threadIdx.x < BINS) hist[threadIdx.x] = wsum[wave] + incl - v;  // bin start inside the workgroup's range
     __syncthreads();
     const uint32_t idx = want ? wsum[16] + hist[key] + rank : 0u;
     __syncthreads();  // lds is reused by the next append
@@ -390,6 +398,24 @@ __device__ __forceinline__ uint32_t ray_sort_key(const float4* __restrict__ node
     const uint32_t ux = (uint32_t)(cx < 0 ? 0 : cx > 3 ? 3 : cx), uy = (uint32_t)(cy < 0 ? 0 : cy > 3 ? 3 : cy), uz = (uint32_t)(cz < 0 ? 0 : cz > 3 ? 3 : cz);
     const uint32_t oct = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
     return (oct << 6) | (uz << 4) | (uy << 2) | ux;
+}
+
+// Sort keys that predict WORK rather than locality (tune_sort_rays = 2; 64 bins): rays that sit next to each other in the queue are
+// taken by the same wave's refill, and lanes whose rays end at about the same time leave fewer lanes waiting for the next refill.
+// Shadow rays: the segment's length in quarter-octaves (a segment is traversed end to end unless it is occluded; its node count
+// grows with its length).  Bounce rays: how steeply the direction leaves the scene's long axis (rays along the soup's slab cross
+// more of it) - the largest |component| of the direction picks the axis, its magnitude 16 steps.
+__device__ __forceinline__ uint32_t shadow_work_key(v3 d) {
+    const float l2 = dot(d, d);                                             // squared length: two quarter-octave steps per octave of length
+    const int e = (int)((__float_as_uint(l2) >> 21) & 0x3ffu) - (125 << 2);  // exponent and two mantissa bits, offset so that |d| = 0.5 .. 128 maps to 0 .. 63
+    return (uint32_t)(e < 0 ? 0 : e > 63 ? 63 : e);
+}
+__device__ __forceinline__ uint32_t bounce_work_key(v3 d) {
+    const float ax = __builtin_fabsf(d.x), ay = __builtin_fabsf(d.y), az = __builtin_fabsf(d.z);
+    const uint32_t axis = ax >= ay && ax >= az ? 0u : ay >= az ? 1u : 2u;
+    const float m = axis == 0u ? ax : axis == 1u ? ay : az;  // 0.577 .. 1
+    const int q = (int)((m - 0.5f) * 32.0f);
+    return axis * 16u + (uint32_t)(q < 0 ? 0 : q > 15 ? 15 : q);
 }
 
 // camera ray of sample s of pixel (px, py): fragment.glsl:129-133 with the pixel-centre 0.5 replaced by a random offset
@@ -1226,7 +1252,16 @@ __global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, con
             }
         }
         uint32_t bi, si;
-        if (sort_rays) {  // wave-uniform
+        if (sort_rays == 2u) {  // wave-uniform
+            uint32_t kb = 0, ks = 0;
+            if (bounce) {
+                const float4 rd = st.ray_d[pid];
+                kb = bounce_work_key(mk(rd.x, rd.y, rd.z));
+            }
+            if (shadow) ks = shadow_work_key(mk(sd.x, sd.y, sd.z));
+            bi = block_append_sorted<64>(bounce, kb, &next_ctr[PT_CTR_COUNT], lds);
+            si = block_append_sorted<64>(shadow, ks, &next_ctr[PT_CTR_SHADOW_COUNT], lds);
+        } else if (sort_rays) {
             uint32_t kb = 0, ks = 0;
             if (bounce) {
                 const float4 ro = st.ray_o[pid], rd = st.ray_d[pid];
@@ -1394,9 +1429,9 @@ int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const Pt
 }
 
 int launch_pt_shade(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr,
-                    uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid, bool sort_rays) {
+                    uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid, uint32_t sort_rays) {
     hipLaunchKernelGGL(pt_shade, dim3(grid), dim3(kAppendThreads), 0, c->stream, sc, f, st, queue, count_ptr, depth, next_queue, next_ctr,
-                       (uint32_t)(sort_rays ? 1 : 0));
+                       sort_rays);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }

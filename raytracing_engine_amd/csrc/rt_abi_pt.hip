@@ -312,7 +312,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             {
                 rt::RoctxRange rr("rt.path_b.shade depth", d);
                 tm.begin(2);
-                if (int rc = rt::launch_pt_shade(c, sc, f, pt.st, d == 0 && packet ? nullptr : q, ctr_d + rt::PT_CTR_COUNT, d, qn, ctr_n, grid_stride, prm->tune_sort_rays != 0)) return rc;
+                if (int rc = rt::launch_pt_shade(c, sc, f, pt.st, d == 0 && packet ? nullptr : q, ctr_d + rt::PT_CTR_COUNT, d, qn, ctr_n, grid_stride, prm->tune_sort_rays)) return rc;
                 tm.end();
             }
             if (pt.n_lights) {

@@ -288,7 +288,7 @@ int launch_pt_trace_fused(Ctx* c, const PtScene& sc, const PtState& st, const ui
 uint32_t pt_pool_lds_bytes(uint32_t tri_mode);  // static LDS a 256-thread workgroup of the per-lane kernels needs beyond the stacks and the octant table
 int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count);
 int launch_pt_shade(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr,
-                    uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid, bool sort_rays);
+                    uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid, uint32_t sort_rays);
 int launch_pt_resolve(Ctx* c, const PtFrame& f, const PtState& st, float* acc, float* dst, int tile_major);
 int launch_pt_trace_rays(Ctx* c, const PtScene& sc, const float* origins, const float* dirs, uint32_t n, int any_hit, float* t_out,
                          int* tri_out, uint32_t* counts, const StackCfg& sk, uint32_t grid);

@@ -133,7 +133,7 @@ int main(int argc, char** argv) {
                     tn = std::fmax(tn, t_near);
                     tf = std::fmin(tf, t_far);
                 }
-                if (!(tn <= tf)) continue;
+                if (std::signbit(tf - tn)) continue;  // the kernels collect sign bits of tf - tn (node_step in csrc/path_b.hip)
                 if (inner) inner_hit |= 1u << ((uint32_t)slot ^ oct_inv);
                 else leaf_hit |= 1u << slot;
             }

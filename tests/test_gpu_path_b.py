@@ -247,7 +247,7 @@ def _knob_scene():
                                    dict(tune_tri_mode=3, tune_no_overlap=2, tune_refill_min=64),
                                    dict(tune_tri_mode=4), dict(tune_tri_mode=4, tune_refill_min=1), dict(tune_tri_mode=4, tune_refill_min=64), dict(tune_tri_mode=4, tune_refill_min=24 | (3 << 8)),
                                    dict(tune_tri_mode=4, tune_no_packet=1, tune_no_overlap=1, tune_lds_stack=1), dict(tune_tri_mode=4, tune_no_overlap=2, tune_blocks_per_cu=1),
-                                   dict(tune_tri_mode=4, tune_sort_rays=1)])
+                                   dict(tune_tri_mode=4, tune_sort_rays=1), dict(tune_sort_rays=2), dict(tune_sort_rays=2, tune_no_packet=1, tune_refill_min=8)])
 def test_scheduling_knobs_do_not_change_the_frame(renderer, knobs):
     """Refill threshold, triangle tests per round, inline / wave-pooled triangle tests and the pool's flush rule, resident
     workgroups, LDS / spill split of the traversal stack, rays sorted in LDS, launch overlap: pure scheduling, so the frame and
