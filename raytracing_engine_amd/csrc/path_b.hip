@@ -784,6 +784,7 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
 // the node fetches in between (vector memory returns in order).  A lane that finishes takes the next ray out of LDS as soon as
 // `pop_min` lanes are idle (default 8).  The rays in flight chip-wide grow by at most kPfRing per wave (25 %).
 constexpr uint32_t kPfRing = 16, kPfBatch = 8;
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef float f4v __attribute__((ext_vector_type(4)));  // native vector: HIP's float4 class has no address-space-qualified members
 typedef __attribute__((address_space(3))) f4v lds_f4;
 
@@ -1103,11 +1104,15 @@ __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const P
             }
             const uint32_t slot = (bit - 24u) ^ oct;
             const uint32_t node = gx + (uint32_t)__builtin_popcount(hits & ~(0xffffffffu << slot));
-            const uint32_t* __restrict__ nd = reinterpret_cast<const uint32_t*>(sc.nodes) + (size_t)node * 20u;
+            const uint32_t* __restrict__ nd = reinterpret_cast<const uint32_t*>(sc.nodes) + (size_t)uniform(node) * 20u;
             if (COUNT) n_nodes++;
-            // header: wave-uniform address -> scalar loads
-            const float px_ = __uint_as_float(nd[0]), py_ = __uint_as_float(nd[1]), pz_ = __uint_as_float(nd[2]);
-            const uint32_t w3 = nd[3], child_base = nd[4], tri_base = nd[5], leafmask = nd[6] & 0xffu;
+            // header: the address is wave-uniform, so the 32 bytes come through the SCALAR cache into scalar registers.  Written as an
+            // s_load: left to itself the compiler issues vector loads of the one address (it cannot rule out that the kernel's own
+            // stores alias the node array) and moves the seven words to scalar registers with seven v_readfirstlane
+            u32x8 hdr;
+            asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hdr) : "s"(nd) : "memory");
+            const float px_ = __uint_as_float(hdr[0]), py_ = __uint_as_float(hdr[1]), pz_ = __uint_as_float(hdr[2]);
+            const uint32_t w3 = hdr[3], child_base = hdr[4], tri_base = hdr[5], leafmask = hdr[6] & 0xffu;
             const float sx = __uint_as_float((w3 & 0xffu) << 23), sy = __uint_as_float(((w3 >> 8) & 0xffu) << 23), sz = __uint_as_float(((w3 >> 16) & 0xffu) << 23);
             const uint32_t imask = w3 >> 24;
             // cooperative decode: one 48-byte vector load for the wave, world-space plane = p + q * scale
@@ -1124,7 +1129,10 @@ __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const P
                 const float2 b = *reinterpret_cast<const float2*>(&planes[c * 8 + 4]);  // far y, z
                 const float tn = fmax_(fmax_(__builtin_fmaf(a.x, inv.x, noi.x), __builtin_fmaf(a.y, inv.y, noi.y)), fmax_(__builtin_fmaf(a.z, inv.z, noi.z), 0.0f));
                 const float tf = fmin_(fmin_(__builtin_fmaf(a.w, inv.x, noi.x), __builtin_fmaf(b.x, inv.y, noi.y)), fmin_(__builtin_fmaf(b.y, inv.z, noi.z), best.t));
-                any |= (__builtin_amdgcn_ballot_w64(tn <= tf) & act_mask) ? (1u << c) : 0u;
+                // (scalar arithmetic on the ballot, no bool: a uniform i1 is kept as a lane mask and the select comes back through
+                // v_cndmask + v_readfirstlane, two vector instructions per child)
+                const uint32_t hit_lanes = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(tn <= tf) & act_mask);
+                any |= (hit_lanes < 1u ? hit_lanes : 1u) << c;
             }
             // wave-uniform bookkeeping, branch-free on the scalar unit: inner children to enter, keyed by
             // slot ^ octant (front to back), and the triangles of the leaf children that were hit
