@@ -983,11 +983,12 @@ struct PoolLds<TRI_INLINE_PF> {
 };
 constexpr uint32_t kPoolLdsBytes = 4u * (kPoolRing * 8u + 64u * 8u + 64u * 4u);
 constexpr uint32_t kPfLdsBytes = 4u * 2u * kPfRing * 16u;
+constexpr int kInlineWaves = 8;  // (7 = 72 VGPRs compiles to the same instruction count)
 constexpr int kPfWaves = 6;    // TRI_INLINE_PF: the prefetch registers (two 16-byte tuples, index, slot) do not fit 72 VGPRs without spills in the loop
 constexpr int kPoolWaves = 7;  // waves per SIMD the TRI_POOL / TRI_DEFER kernels are compiled for (72 VGPRs; the default stack split leaves room for seven workgroups per CU anyway)
 
 template <bool ANY, bool COUNT, int MODE>
-__global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : MODE == TRI_INLINE_PF ? kPfWaves : kPoolWaves) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, MODE == TRI_INLINE ? kInlineWaves : MODE == TRI_INLINE_PF ? kPfWaves : kPoolWaves) void pt_trace(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
                                                 const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ head,
                                                 unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min, uint32_t tri_cfg) {
     extern __shared__ unsigned long long lds_stack[];  // sk.lds_cap x 256 entries
@@ -1005,7 +1006,7 @@ __global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : MODE == TRI_INLINE_PF
 // closest-hit queue - the frame's critical path: shade(d + 1) waits for it - and moves on to the shadow queue when that one
 // is dry, instead of leaving the machine to the few long rays of a launch's tail.  One tail per bounce instead of two.
 template <bool COUNT, int MODE>
-__global__ __launch_bounds__(256, MODE == TRI_INLINE ? 8 : MODE == TRI_INLINE_PF ? kPfWaves : kPoolWaves) void pt_trace_fused(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, MODE == TRI_INLINE ? kInlineWaves : MODE == TRI_INLINE_PF ? kPfWaves : kPoolWaves) void pt_trace_fused(const PtScene sc, PtState st, const uint32_t* __restrict__ queue,
                                                       const uint32_t* __restrict__ closest_count, uint32_t* __restrict__ closest_head,
                                                       const uint32_t* __restrict__ shadow_count, uint32_t* __restrict__ shadow_head,
                                                       unsigned long long* __restrict__ stats, const StackCfg sk, uint32_t refill_min, uint32_t tri_cfg) {
