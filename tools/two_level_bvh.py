@@ -5,12 +5,13 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import raytracing_engine_amd as R
+CHUNKS = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["64"])]  # python tools/two_level_bvh.py 8,64,512
 r = R.Renderer(0)
 for n, edge in ((100_000, 0.25), (1_000_000, 0.08)):
     mesh = R.scenes.soup_scene(n, seed=1, edge=edge)
     r.resize(1920, 1080)
-    for levels in (1, 2):
-        r.set_mesh(*mesh, bvh_levels=levels)
+    for levels, chunks in [(1, 0)] + [(2, c) for c in CHUNKS]:
+        r.set_mesh(*mesh, bvh_levels=levels, blas_chunks=chunks)
         st = r.pt_stats()
         info = {k: st[k] for k in ("n_nodes", "bvh_depth", "bvh_levels", "blas_chunks", "tlas_nodes")}
         info.update({k: round(st[k], 2) for k in ("bvh_build_ms", "ms_build_blas", "ms_build_tlas", "ms_build_flatten")})
@@ -24,8 +25,10 @@ for n, edge in ((100_000, 0.25), (1_000_000, 0.08)):
         print(n, "levels", levels, info, "ms/frame %.3f" % np.median(ms), "Mrays/s %.0f" % (rays / np.median(ms) / 1e3),
               "shadow nodes/ray %.2f" % (c["shadow_nodes_visited"] / c["shadow_rays"]), "closest fetches", c["nodes_visited"], flush=True)
         if levels == 2:
+            sizes = [len(r.mesh_chunk(c)) for c in range(st["blas_chunks"])]
+            print("   chunk sizes: min %d max %d" % (min(sizes), max(sizes)), flush=True)
             ids = r.mesh_chunk(7)
-            v2 = mesh[0][ids] + np.float32(0.01)
+            v2 = mesh[0][ids] * np.float32(0.999)  # moved, and inside the coordinate range the mesh was padded for
             t0 = time.perf_counter(); r.update_mesh_chunk(7, v2); dt = (time.perf_counter() - t0) * 1e3
             st = r.pt_stats()
             print("   chunk rebuild: wall %.2f ms (blas %.2f, tlas %.3f, flatten %.2f)" % (dt, st["ms_build_blas"], st["ms_build_tlas"], st["ms_build_flatten"]), flush=True)
