@@ -456,13 +456,16 @@ class TriWorkload:
                             f"{self.bounces} bounce + NEE, path B wavefront path tracer (camera rays: packet kernel)"
                             + (f" [RT_BENCH_TUNE: {tune}]" if tune else ""),
                 "width": self.width, "height": self.height, "spp": self.spp, "bounces": self.bounces, "tile": 64,
-                "bvh_build_ms_host": round(st["bvh_build_ms"], 1)}
+                "bvh_build_ms_host": round(st["bvh_build_ms"], 1),
+                "persistent_workgroups_per_cu": int(self.params.tune_blocks_per_cu) or "context default (7 for a whole frame)"}
 
     def set_share(self, world, n_lanes):
         """A rank's share of the frame and the frame lanes it is rendered on: with a 1/8 share on several lanes the persistent
         traversal launches of the lanes fill the machine TOGETHER, and two workgroups per CU per launch instead of the four
         the context would pick for a lone frame of that size measured best (tools/partition_scaling.py --tune
-        tune_blocks_per_cu=2: 1.43 against 1.48 ms per frame with three lanes; profiles/r03_partition_scaling.txt)."""
+        tune_blocks_per_cu=2: 1.43 against 1.48 ms per frame with three lanes; profiles/r03_partition_scaling.txt).  For the
+        whole frame the same idea (4 instead of 7 workgroups per CU with three lanes) measured 8.91-8.93 against 9.05-9.10 ms in
+        some runs and 9.36 in others (same file): not applied."""
         if world >= 8 and n_lanes >= 2 and "tune_blocks_per_cu" not in tune_from_env():
             self.params.tune_blocks_per_cu = 2
 
