@@ -272,6 +272,18 @@ def test_queue_streams_cover_every_entry_exactly_once(renderer):
         check_pt(renderer, mesh, w, h, pos=(0, 1, 0), spp=1, bounces=2, seed=w * 31 + h)
 
 
+@pytest.mark.parametrize("tri_mode", [2, 3, 4])
+def test_experimental_schedules_on_short_and_ragged_queues(renderer, tri_mode):
+    """The wave-pooled (2), postponed (3) and prefetch-ring (4) schedules of the per-lane kernels on queue lengths around the
+    block / stream / ring boundaries (1 ray, fewer rays than a prefetch batch, one more than a wave, ...), where their drain
+    and exit rules are exercised with nearly empty rings: frames and ray counts equal to the oracle's."""
+    mesh = scenes.cornell_tri_scene()
+    for w, h in [(1, 1), (3, 2), (7, 1), (9, 1), (8, 8), (65, 1), (33, 31), (129, 17)]:
+        check_pt(renderer, mesh, w, h, pos=(0, 1, 0), spp=1, bounces=3, seed=w * 31 + h, tune_tri_mode=tri_mode, tune_no_packet=(w * h) % 2)
+    check_pt(renderer, scenes.soup_scene(3000, seed=5, edge=1.0), 40, 30, spp=3, bounces=2, seed=6, sky=(0.1, 0.1, 0.1), tune_tri_mode=tri_mode, tune_refill_min=2)
+
+
+
 def test_far_camera_within_the_padded_range_and_rejection_beyond(renderer):
     """The ray/box test's rounding error grows with the distance of the ray origin; the box padding covers
     camera coordinates up to 32 x the mesh's largest |coordinate| (include/rt_abi.h, rt_render_pt).  A
