@@ -130,3 +130,26 @@ def test_config4_tri1m_4k_64spp_8bounces(renderer, tri1m):
     assert np.array_equal(rgb[rows[0]:rows[1]], band)
     assert ct["camera_rays"] == w * 2 * 64 and ct["bounce_rays"] > ct["camera_rays"]
     renderer.resize(64, 64)  # leave a small view behind for the tests that follow
+
+
+def test_context_tri16m_scene_beyond_the_infinity_cache(renderer):
+    """bench.py's context workload tri16m_1080p_4spp: the headline soup with 16 M triangles (1.6 GB of nodes, triangle records and
+    materials = six times the 256 MiB Infinity Cache), the one scene on which the kernels run against HBM.  Two bands of the
+    full-size frame bit for bit against oracle B (its own BVH2 over the 16 M triangles), stack within bounds.  (Last in the file:
+    it replaces the module's 1 M-triangle mesh.)"""
+    mesh = scenes.soup_scene(16_000_000, seed=1, edge=0.032)
+    renderer.set_partition(0, 1)
+    renderer.resize(1920, 1080)
+    renderer.set_mesh(*mesh)
+    st = renderer.pt_stats()
+    assert st["n_tris"] == 16_000_000 and st["n_nodes"] * 80 + st["n_tris"] * 80 > 4 * (256 << 20)
+    rgb = renderer.render_pt(spp=4, bounces=1, seed=1, sky=SKY)
+    st = renderer.pt_stats()
+    assert st["stack_overflow"] == 0 and np.isfinite(rgb).all() and st["camera_rays"] == 1920 * 1080 * 4
+    sc = O.TriScene(*mesh)
+    for rows in [(270, 272), (806, 808)]:
+        band, _ = sc.render(1920, 1080, spp=4, bounces=1, seed=1, sky=SKY, rows=rows)
+        assert np.array_equal(rgb[rows[0]:rows[1]], band), rows
+    del sc
+    renderer.set_mesh(*scenes.cornell_tri_scene())  # release the 1.6 GB
+    renderer.resize(64, 64)
