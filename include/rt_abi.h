@@ -260,8 +260,11 @@ typedef struct rt_pt_params {
                                     1 = inline (every round ends with a triangle phase for the lanes that hold a leaf hit),
                                     2 = wave-pooled (leaf hits go to a per-wave ring in LDS; the whole wave tests 64 of them at once,
                                     results merged with a 64-bit LDS minimum on (t, triangle id)).  Pooled mode: byte 1 = groups in the
-                                    ring that trigger a flush (0 = default), byte 2 = rounds a group may wait (0 = default).  Frames do
-                                    not depend on any of it. */
+                                    ring that trigger a flush (0 = default), byte 2 = rounds a group may wait (0 = default).
+                                    3 = postponed tests (bytes 1-2: holding / stuck lanes that trigger the phase), 4 = inline with a
+                                    software-pipelined refill (a ring of ready rays per wave in LDS).  Inline mode, byte 1 bit 0: the
+                                    fused launch as two loops one after the other instead of one loop with a per-lane ray kind.
+                                    Frames do not depend on any of it. */
 } rt_pt_params;
 
 typedef struct rt_pt_stats {

@@ -269,6 +269,29 @@ __device__ __forceinline__ bool tri_step(const float4* __restrict__ tris, TRay& 
     return false;
 }
 
+// tri_step for a wave whose lanes carry both kinds of ray (trace_queue_mixed): the kind is a per-lane flag.
+template <bool COUNT>
+__device__ __forceinline__ bool tri_step_mixed(const float4* __restrict__ tris, TRay& r, Hit& best, Group& T, TravCounters& tc, bool is_any) {
+    const uint32_t bit = (uint32_t)__builtin_ctz(T.y);
+    T.y &= T.y - 1u;
+    const uint32_t li = T.x + (uint32_t)__builtin_popcount((T.y >> 8) & ~(0xffffffffu << bit));
+    const float4* tp = tris + (size_t)li * 3;
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    if (COUNT) tc.tris++;
+    float t;
+    if (tri_test(r.o, r.d, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t) && t > 0.0f) {
+        if (is_any) return t < kShadowTmax;
+        const uint32_t id = __float_as_uint(c.y);
+        if (t < best.t || (t == best.t && id < best.id)) {
+            best.t = t;
+            best.li = (int)li;
+            best.id = id;
+            r.tmax = t;
+        }
+    }
+    return false;
+}
+
 __device__ __forceinline__ Group root_group() { return Group{0u, 0x80000000u}; }  // "child 0 of nothing" = node 0
 
 // Whole-ray traversal for one lane (used by the rt_trace_rays test hook; the render kernels drive
@@ -774,6 +797,160 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
     if (tc.overflow) atomicOr((unsigned int*)&stats[2], 1u);
 }
 
+// ---- one loop for both queues of a fused launch ---------------------------------------------------
+// trace_queue<closest> followed by trace_queue<any> makes every wave DRAIN between the two: once the closest-hit queue is dry a
+// wave gets no refills, its lanes run out one by one (a tenth of its rounds, at nine of 64 lanes alive) and only then does it
+// turn to the shadow queue.  The node step is the same for both kinds of ray and the triangle step differs only in what a hit
+// means, so here the kind is a per-lane flag: when the closest-hit queue is dry the wave's idle lanes are refilled from the shadow
+// queue while its last closest-hit rays are still walking.  One tail per wave and launch instead of two.  Every ray is traced by
+// exactly the step functions of the separate loops, so frames and counts are unchanged.
+template <bool COUNT>
+__device__ __forceinline__ void trace_queue_mixed(const PtScene& sc, const PtState& st, const uint32_t* __restrict__ queue,
+                                                  const uint32_t* __restrict__ closest_count, uint32_t* __restrict__ closest_head,
+                                                  const uint32_t* __restrict__ shadow_count, uint32_t* __restrict__ shadow_head,
+                                                  unsigned long long* __restrict__ stats, TravStack& stk, const uint8_t* perm_lut, uint32_t refill_min) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t n_closest = uniform(*closest_count), n_shadow = uniform(*shadow_count);
+    const int tris_per_round = (int)((refill_min >> 8) & 0xffu) ? (int)((refill_min >> 8) & 0xffu) : kTrisPerRound;
+    refill_min &= 0xffu;
+    TravCounters tc{0, 0, 0};                          // COUNT: the current ray of this lane
+    uint32_t cl_nodes = 0, cl_tris = 0, any_nodes = 0, any_tris = 0;  // COUNT: retired rays of this lane, by kind
+
+    TRay r = make_tray(mk(0.0f, 0.0f, 0.0f), mk(0.0f, 1.0f, 0.0f), 0.0f);
+    Hit best{0.0f, -1, 0u};
+    Group G{0u, 0u}, T{0u, 0u};
+    uint32_t slot = 0;  // closest: path id; any-hit: shadow-queue index
+    bool has_ray = false, occluded = false, alive = false;
+    bool is_any = false;  // the kind of this lane's ray
+    // wave-uniform: which queue the wave refills from, and its state
+    uint32_t phase = n_closest == 0u ? 1u : 0u;  // 0 = closest-hit queue, 1 = shadow queue
+    uint32_t n = phase == 0u ? n_closest : n_shadow;
+    uint32_t* head = phase == 0u ? closest_head : shadow_head;
+    bool exhausted = n == 0u;  // both queues dry
+    const uint32_t stream0 = uniform((blockIdx.x * 4u + (threadIdx.x >> 6)) & (PT_HEADS - 1u));
+    uint32_t stream = stream0, dry_streams = 0;
+    uint32_t rounds = 0, alive_rounds = 0;  // COUNT only
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!alive);
+        if (idle == ~0ull || (!exhausted && (uint32_t)__popcll(idle) >= refill_min)) {
+            if (!alive && has_ray) {  // retire
+                if (is_any) {
+                    if (!occluded) {
+                        const uint32_t pid = __float_as_uint(st.sh_o[slot].w);
+                        const float4 c = st.sh_c[slot];
+                        float4 L = st.rad[pid];
+                        L.x += c.x;
+                        L.y += c.y;
+                        L.z += c.z;
+                        st.rad[pid] = L;
+                    }
+                    if (COUNT) {
+                        any_nodes += tc.nodes;
+                        any_tris += tc.tris;
+                    }
+                } else {
+                    st.hit[slot] = make_float2(best.t, __int_as_float(best.li));
+                    if (COUNT) {
+                        cl_nodes += tc.nodes;
+                        cl_tris += tc.tris;
+                    }
+                }
+                if (COUNT) tc.nodes = tc.tris = 0;
+                has_ray = false;
+            }
+            if (!exhausted) {
+                // (as trace_queue: one returning atomic on the wave's stream head reserves what the idle lanes need)
+                const uint32_t want = (uint32_t)__popcll(idle);
+                const uint32_t my_rank = (uint32_t)__popcll(idle & lt_mask);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head + stream * PT_HEAD_STRIDE, want);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t j = base + my_rank, je = base + want;
+                const uint32_t i = !alive ? ((((j >> 6) * PT_HEADS + stream) << 6) | (j & 63u)) : n;
+                const bool take = !alive && i < n;
+                if (take) {
+                    if (phase != 0u) {
+                        const float4 so = st.sh_o[i], sd = st.sh_d[i];
+                        r = make_tray(mk(so.x, so.y, so.z), mk(sd.x, sd.y, sd.z), kShadowTmax);
+                        slot = i;
+                        occluded = false;
+                        is_any = true;
+                    } else {
+                        slot = queue[i];
+                        const float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
+                        r = make_tray(mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), __builtin_inff());
+                        best = Hit{__builtin_inff(), -1, 0xffffffffu};
+                        is_any = false;
+                    }
+                    has_ray = true;
+                    alive = true;
+                    G = root_group();
+                    T = Group{0u, 0u};
+                    stk.sp = 0;
+                }
+                if (((((je >> 6) * PT_HEADS + stream) << 6) | (je & 63u)) >= n) {  // this stream is dry: move on
+                    stream = (stream + 1u) & (PT_HEADS - 1u);
+                    if (++dry_streams >= PT_HEADS) {  // this queue is dry: on to the shadow queue, or done
+                        if (phase == 0u && n_shadow != 0u) {
+                            phase = 1u;
+                            n = n_shadow;
+                            head = shadow_head;
+                            stream = stream0;
+                            dry_streams = 0u;
+                        } else {
+                            exhausted = true;
+                        }
+                    }
+                }
+            }
+            if (__ballot(alive) == 0ull && exhausted) break;  // both queues drained and every lane retired
+        }
+        if (COUNT) {
+            rounds++;
+            alive_rounds += (uint32_t)__popcll(__ballot(alive));
+        }
+        // node phase: lanes without pending triangles visit their next node
+        if (alive && !has_tris(T)) {
+            if (!has_nodes(G)) {
+                if (stk.sp) G = stk.pop();
+                else alive = false;
+            }
+            if (alive) node_step<COUNT>(sc.nodes, perm_lut, r, G, T, stk, tc);
+        }
+        // triangle phase: one test, then what a hit means to this lane's kind of ray
+#pragma unroll 1
+        for (int it = 0; it < tris_per_round; it++) {
+            if (alive && has_tris(T)) {
+                if (tri_step_mixed<COUNT>(sc.tris, r, best, T, tc, is_any)) {
+                    occluded = true;
+                    alive = false;
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        unsigned long long a = cl_nodes, b = cl_tris, c = any_nodes, d = any_tris;
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
+            c += __shfl_down(c, off);
+            d += __shfl_down(d, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&stats[6], (unsigned long long)rounds);
+            atomicAdd(&stats[7], (unsigned long long)alive_rounds);
+            atomicAdd(&stats[14], (unsigned long long)rounds);
+            atomicAdd(&stats[0], a);
+            atomicAdd(&stats[1], b);
+            atomicAdd(&stats[11], c);
+            atomicAdd(&stats[12], d);
+        }
+    }
+    if (tc.overflow) atomicOr((unsigned int*)&stats[2], 1u);
+}
+
 // ---- software-pipelined refill (TRI_INLINE_PF) ------------------------------------------------------
 // The blocking refill above is three dependent memory round trips (head atomic -> queue entry -> ray) during which the whole
 // wave stands still, plus ~190 vector instructions, and that is why its threshold sits at 24 idle lanes: measured, a refill event
@@ -1019,6 +1196,14 @@ __global__ __launch_bounds__(256, MODE == TRI_INLINE ? kInlineWaves : MODE == TR
     if constexpr (MODE == TRI_INLINE_PF) {
         trace_queue_pf<false, COUNT>(sc, st, queue, closest_count, closest_head, stats, stk, perm_lut, refill_min, pool.ring(threadIdx.x >> 6));
         trace_queue_pf<true, COUNT>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, perm_lut, refill_min, pool.ring(threadIdx.x >> 6), 11u);
+    } else if constexpr (MODE == TRI_INLINE) {
+        if (tri_cfg & 1u) {  // tuning: the two loops one after the other (every wave drains between the queues)
+            const PoolMem pm = pool.get(threadIdx.x >> 6);
+            trace_queue<false, COUNT, MODE>(sc, st, queue, closest_count, closest_head, stats, stk, perm_lut, refill_min, pm, tri_cfg);
+            trace_queue<true, COUNT, MODE>(sc, st, nullptr, shadow_count, shadow_head, stats, stk, perm_lut, refill_min, pm, tri_cfg, 11u);
+        } else {
+            trace_queue_mixed<COUNT>(sc, st, queue, closest_count, closest_head, shadow_count, shadow_head, stats, stk, perm_lut, refill_min);
+        }
     } else {
         const PoolMem pm = pool.get(threadIdx.x >> 6);
         trace_queue<false, COUNT, MODE>(sc, st, queue, closest_count, closest_head, stats, stk, perm_lut, refill_min, pm, tri_cfg);

@@ -238,7 +238,7 @@ def _knob_scene():
                                    dict(tune_blocks_per_cu=3, tune_lds_stack=2), dict(tune_lds_stack=1), dict(tune_lds_stack=40),
                                    dict(tune_no_packet=1), dict(tune_sort_rays=1), dict(tune_sort_rays=1, tune_no_packet=1, tune_no_overlap=1),
                                    dict(tune_no_overlap=1), dict(tune_no_overlap=2),
-                                   dict(tune_tri_mode=1), dict(tune_tri_mode=2), dict(tune_tri_mode=2 | (1 << 8) | (1 << 16)),
+                                   dict(tune_tri_mode=1), dict(tune_tri_mode=1 | (1 << 8)), dict(tune_tri_mode=1 | (1 << 8), tune_refill_min=1), dict(tune_tri_mode=2), dict(tune_tri_mode=2 | (1 << 8) | (1 << 16)),
                                    dict(tune_tri_mode=2 | (64 << 8) | (255 << 16)), dict(tune_tri_mode=2 | (7 << 8) | (3 << 16), tune_refill_min=1),
                                    dict(tune_tri_mode=2, tune_no_packet=1, tune_no_overlap=1, tune_lds_stack=1),
                                    dict(tune_tri_mode=2, tune_no_overlap=2, tune_refill_min=64), dict(tune_tri_mode=2, tune_sort_rays=1, tune_blocks_per_cu=1),
