@@ -214,6 +214,23 @@ def launch_ranks(n):
     return rc
 
 
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: RCCL prints a version banner ("RCCL version : ...", four lines) to
+    stdout when its first communicator comes up, and rank 0's stdout must carry ONE JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def timed_region(step, fence, n_setup, warmup, steps, reset):
     """The contract's bracket: set-up + W untimed warm-up steps, then EXACTLY K steps between two fences
     (device synchronisation + barrier over the ranks)."""
@@ -695,10 +712,12 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if args.rehearse_one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        with stdout_to_stderr():
+            if args.rehearse_one_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()  # brings the communicator up (and its banner out) here, not inside the first timed gather
 
     r = R.Renderer(local_rank)  # raises when librt_amd.so / the GPU is missing: no fallback
     wl = WORKLOADS[args.workload](R, r)
