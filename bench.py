@@ -842,6 +842,18 @@ def main():
             # timed region (for N > 1 the gathered, de-tiled frame on rank 0) against the oracle, same process
             out["parity"] = wl.parity(timed_frame, int(rays))
         if not multi:
+            # the regime the roofline block is measured in, next to the timed one: the same K steps on lane 0 alone, one frame after the
+            # other (per-kernel HIP-event durations in `roofline` are those of a frame that has the GPU to itself; with several lanes the
+            # kernels of different frames run side by side and stretch each other while the frame rate goes up)
+            if n_lanes > 1:
+                r.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    wl.step(frame.data_ptr(), False)
+                r.synchronize()
+                one = (time.perf_counter() - t0) / args.steps
+                out["one_frame_at_a_time"] = {"ms_per_step": round(one * 1e3, 4), "value": round(rays / one / 1e6, 3),
+                                              "note": "lane 0 alone after the timed region; `roofline.avg_kernel_ms` belongs to this regime"}
             rl = wl.roofline()
             tr = None if args.no_traffic else measure_traffic(args.workload, wl.dominant_kernel)
             out["roofline"] = finish_roofline(rl, tr)
