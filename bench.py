@@ -123,8 +123,8 @@ def measure_traffic(workload, kernel_substr):
 # kernels use (v_cvt_f32_ubyteN, v_max3 / v_min3, v_cmp, v_cndmask, shifts, bit-field and logic ops, integer multiplies) 4.3-4.8.
 VALU_FAST_CYCLES, VALU_OTHER_CYCLES = 2.75, 4.7
 # Share of the fast class among the vector instructions of the per-lane traversal kernels' code (static count over the ISA of
-# pt_trace_fused: 310 of 1180; the node step itself is 96 fma / cvt pairs in 192): tools/valu_mix.py prints it from the built library.
-VALU_FAST_SHARE = 0.26
+# pt_trace_fused: 0.32; the node step alone: 54 fast-class instructions in 183): tools/valu_mix.py prints it from the built library.
+VALU_FAST_SHARE = 0.32
 N_SIMDS = 256 * 4
 
 
@@ -141,7 +141,7 @@ def measure_valu_issue(workload, kernel_substr):
             "kernel_cycles": round(cycles), "issue_cycles_per_instruction": round(avg, 2),
             "frac": round(insts * avg / (N_SIMDS * max(cycles, 1.0)), 3),
             "sq_active_inst_valu_frac": round(got["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * max(cycles, 1.0)), 3),
-            "definition": "SQ_INSTS_VALU x issue cycles per instruction (0.26 x 2.75 + 0.74 x 4.7, tools/valu_rate_bench.hip at 8 waves per SIMD) / "
+            "definition": "SQ_INSTS_VALU x issue cycles per instruction (0.32 x 2.75 + 0.68 x 4.7: tools/valu_mix.py, tools/valu_rate_bench.hip at 8 waves per SIMD) / "
                           "(1024 SIMDs x GRBM_GUI_ACTIVE / 8); about 1 = every issue slot taken (the isolated-stream costs overstate a mixed "
                           "stream by a few per cent); lanes_per_instruction = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU of the same pass; "
                           "sq_active_inst_valu_frac = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / the same denominator"}
