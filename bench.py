@@ -40,8 +40,9 @@ def parse():
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # run under rocprofv3 by measure_traffic()
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child runs (roofline.traffic = null)")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
-                    help="frame lanes: consecutive steps go round-robin to this many independent contexts (own stream, own "
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frame lanes (0 = the workload's default: 3 for path B, 4 for path A - one per hardware queue, measured "
+                         "0.406 against 0.432 ms per step with 3): consecutive steps go round-robin to this many independent contexts (own stream, own "
                          "pyramid / wavefront state, own output and exchange buffers), so the latency-bound parts of a frame - "
                          "coarse pyramid levels, the tails of the persistent traversal kernels, the RCCL gather - overlap with "
                          "the next frames; 1 = strictly one frame after the other")
@@ -323,6 +324,7 @@ class SpheresWorkload:
     (reference-faithful cone marcher + shading; 4 spp = 2x2 stratified full frames, averaged)."""
 
     name = "spheres8_1080p_4spp"
+    default_lanes = 4  # HIP streams of one priority are dealt onto four hardware queues: one lane per queue (a fifth shares one and loses)
     width, height, spp = 1920, 1080, 4
     dtype = "f32"
     dominant_kernel = "shade_kernel"
@@ -736,7 +738,7 @@ def main():
     # Frame lanes: lane 0 is (r, wl); the others are further contexts with the same scene.  Step i runs on
     # lane i % L.  Inside a lane everything is stream-ordered: render -> [RCCL gather -> de-tile]; lanes only
     # share the GPU (and the communicator, whose gathers are issued in step order on every rank).
-    n_lanes = 1 if args.rehearse_one_gpu else max(1, min(args.frames_in_flight, 8))
+    n_lanes = 1 if args.rehearse_one_gpu else max(1, min(args.frames_in_flight or getattr(wl, "default_lanes", 3), 8))
 
     class Lane:
         pass
