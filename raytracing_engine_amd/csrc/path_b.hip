@@ -1355,6 +1355,219 @@ __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const P
     if (overflow && lane == 0) atomicOr((unsigned int*)&stats[2], 1u);
 }
 
+// ---- packet trace, interval form ---------------------------------------------------------------------
+// The same walk with the node test in two steps.  (1) ONE interval test per child for the whole pass, on 8 lanes per child:
+// the rays of a pass share their origin and the signs of their direction, so with [imin, imax] the range of 1 / d over the
+// pass's lanes (per axis) every lane's slab distance (plane - o) * inv lies between the products with the two ends; lane
+// 8c + k holds plane k of child c (k = 0..2 near x y z, 4..6 far x y z, 3 / 7 the constants 0 and -(largest best.t)),
+// turns it into a LOWER bound of t_near resp. of -t_far (widened by the rounding of the lanes' own fma form), and two
+// quad-wide DPP maxima + one half-row mirror give  max(lower bounds of t_near, 0) <= min(upper bounds of t_far, best)  in
+// lane 8c: ten vector instructions for all eight children.  (2) Only children that pass - 1.2 of 8 on the metric's scene
+// are hit by any ray - get the per-ray slab test of the kernel above (planes parked in LDS as there); PURE skips (2) and
+// enters every child that passes (1).  Both walk a superset of the boxes each ray would visit alone and test every
+// triangle with the ray's own arithmetic, so frames are unchanged.
+typedef __attribute__((address_space(3))) float lds_f32;
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// v = max(v, v of the lane the DPP control names); written out because the builtin form (v_mov_dpp, then fmaxf) pays a
+// canonicalising v_max per operand.  s_nop 1: a DPP read of a VGPR needs two wait states behind the VALU write, which the
+// compiler does not insert for text it does not parse.
+#define RT_DPP_MAX(v, ctrl) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(v))
+// largest of a wave-uniform set of NON-NEGATIVE floats, one per lane (integer order = float order): rows by DPP, then the scalar unit
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    RT_DPP_MAX(v, "quad_perm:[1,0,3,2]");
+    RT_DPP_MAX(v, "quad_perm:[2,3,0,1]");
+    RT_DPP_MAX(v, "row_half_mirror");
+    RT_DPP_MAX(v, "row_mirror");
+    const uint32_t b = __float_as_uint(v);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)b, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)b, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)b, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)b, 48);
+    const uint32_t m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
+    return __uint_as_float(m01 > m23 ? m01 : m23);
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmin_(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax_(v, __shfl_xor(v, off));
+    return v;
+}
+// bit 0 of each of the 8 bytes of m -> bits 0..7 (multiply-gather: the partial products land on distinct bits)
+__device__ __forceinline__ uint32_t gather_byte_lsbs(unsigned long long m) {
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    return (((lo * 0x00204081u) >> 21) & 0xfu) | ((((hi * 0x00204081u) >> 21) & 0xfu) << 4);
+}
+
+template <bool COUNT, bool PURE, bool FARCAP>
+__global__ __launch_bounds__(256) void pt_trace_packet_ia(const PtScene sc, const PtFrame f, PtState st, unsigned long long* __restrict__ stats) {
+    __shared__ f4v s_planes[4][16];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    lds_f32* planes = (lds_f32*)s_planes[wv];
+    lds_f4* planes4 = (lds_f4*)s_planes[wv];
+    const uint32_t pid = (blockIdx.x * 4u + wv) * 64u + lane;
+
+    bool alive = false;
+    v3 d = mk(0.0f, 1.0f, 0.0f);
+    if (pid < f.n_paths) {
+        const uint32_t slot = pid / f.spp_batch;
+        uint32_t px, py, lx, ly, k;
+        alive = slot_pixel(f, slot, px, py, lx, ly, k);
+        if (alive) {
+            d = camera_dir(f, px, py, f.sample0 + (pid - slot * f.spp_batch));
+            st.ray_d[pid] = make_float4(d.x, d.y, d.z, 0.0f);
+        }
+    }
+    const v3 o = mk(f.cam.pos[0], f.cam.pos[1], f.cam.pos[2]);  // wave-uniform
+    const v3 inv = safe_inv(d);
+    const v3 noi = mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+    const uint32_t oct_inv = ((__float_as_uint(d.x) >> 31) ? 0u : 4u) | ((__float_as_uint(d.y) >> 31) ? 0u : 2u) | ((__float_as_uint(d.z) >> 31) ? 0u : 1u);
+    Hit best{__builtin_inff(), -1, 0xffffffffu};
+
+    // lane 8c + k: plane k of child c
+    const uint32_t p_child = lane >> 3, pk = lane & 7u, p_axis = pk & 3u;
+    const bool p_plane = p_axis != 3u, p_far = pk >= 4u;
+    const float o_ax = p_axis == 0u ? o.x : p_axis == 1u ? o.y : o.z;
+    uint32_t n_nodes = 0, n_tris = 0, overflow = 0;  // wave-uniform
+
+    unsigned long long remaining = __ballot(alive);
+    while (remaining) {
+        const uint32_t oct = (uint32_t)__builtin_amdgcn_readlane((int)oct_inv, (int)__builtin_ctzll(remaining));
+        const bool act = alive && oct_inv == oct;
+        const unsigned long long act_mask = __ballot(act);  // wave-uniform
+        remaining &= ~act_mask;
+        // the pass's range of 1 / d per axis (one sign per axis: the octant is shared), and this lane's share of it
+        const float inf = __builtin_inff();
+        const float ix0 = wave_min_f(act ? inv.x : inf), ix1 = wave_max_f(act ? inv.x : -inf);
+        const float iy0 = wave_min_f(act ? inv.y : inf), iy1 = wave_max_f(act ? inv.y : -inf);
+        const float iz0 = wave_min_f(act ? inv.z : inf), iz1 = wave_max_f(act ? inv.z : -inf);
+        const float imin = p_axis == 0u ? ix0 : p_axis == 1u ? iy0 : iz0, imax = p_axis == 0u ? ix1 : p_axis == 1u ? iy1 : iz1;
+        // near lanes bound t from below: min(u * imin, u * imax); far lanes bound -t from below: min(u * -imin, u * -imax)
+        const float ia_a = p_plane ? (p_far ? -imin : imin) : 0.0f, ia_b = p_plane ? (p_far ? -imax : imax) : 0.0f;
+        // widening: a lane computes fma(plane, inv, -(o * inv)), off the exact (plane - o) * inv by at most 2^-24 (|o * inv| + |t|)
+        float ia_m = p_plane ? (__builtin_fabsf(o_ax) * fmax_(__builtin_fabsf(imin), __builtin_fabsf(imax))) * 0x1p-22f : (pk == 3u ? 0.0f : inf);
+        const bool dir_pos = p_plane && ((oct >> (2u - p_axis)) & 1u) != 0u;  // oct bit 4 = x, 2 = y, 1 = z: direction >= 0
+        const uint32_t q_off = p_plane ? 32u + (p_far == dir_pos ? 24u : 0u) + p_axis * 8u + p_child : 32u + p_child;
+        // Lanes 0..15 collect the children's verdicts (one ds_bpermute of lane 8c's value): lane p < 8 reads child slot p ^ oct - the
+        // ballot's bits 0..7 are the hit INNER children in front-to-back order, what the group word wants - and lane 8 + c reads
+        // slot c for the leaves.  v_sh moves the lane's bit of  imask | leafmask << 8  to the sign.
+        const uint32_t v_slot = lane < 8u ? lane ^ oct : lane & 7u;
+        const uint32_t v_addr = lane < 16u ? v_slot * 32u : 0u;
+        const uint32_t v_sh = lane < 8u ? 31u - v_slot : lane < 16u ? 31u - lane : 0u;  // lanes >= 16: bit 31 of the word, always 0
+        const uint32_t p_sh = lane < 8u ? 31u - (lane ^ oct) : 0u;  // (hybrid) bit p ^ oct of a slot-ordered mask to the sign; other lanes: see the & 0xff
+        const uint32_t s_sh = 23u - 8u * (p_axis < 2u ? p_axis : 2u);  // this lane's scale exponent of header word 3 to the exponent field
+        const float w_x = p_axis == 0u ? 1.0f : 0.0f, w_y = p_axis == 1u ? 1.0f : 0.0f, w_z = p_axis >= 2u ? 1.0f : 0.0f;
+
+        // traversal stack in two VGPRs, entry i in lane i (v_writelane / v_readlane with a scalar index: no LDS, no exec games);
+        // render_pt_common sends trees that may need more than kPacketStackEntries (< 64) entries to the per-lane kernel
+        int stx = 0, sty = 0;                // entry 0 = (0, 0): the end marker
+        uint32_t sp = 1, sp_max = 0;
+        uint32_t gx = 0u, gy = 0x80000000u;  // the root group
+        do {  // (gx, gy) holds at least one child
+            const uint32_t lz = (uint32_t)__builtin_clz(gy);  // 0..7: the front-most pending child is bit 31 - lz
+            const uint32_t hits = gy;
+            gy &= ~(0x80000000u >> lz);
+            if (gy > 0x00ffffffu) {  // remaining siblings
+                // (no builtin for v_writelane in this compiler; below gfx10 the lane select has to come through m0 when the value is a
+                // scalar register - one constant-bus operand.  m0 holds nothing of the compiler's here: gfx9 LDS access does not use it)
+                asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(stx), "+v"(sty) : "s"(gx), "s"(gy), "s"(sp));
+                sp++;
+                sp_max = sp_max > sp ? sp_max : sp;
+            }
+            const uint32_t slot = (7u - lz) ^ oct;
+            const uint32_t node = gx + (uint32_t)__builtin_popcount(hits & ((1u << slot) - 1u));
+            const uint32_t* __restrict__ nd = reinterpret_cast<const uint32_t*>(sc.nodes) + (size_t)uniform(node) * 20u;
+            if (COUNT) n_nodes++;
+            const uint32_t q = reinterpret_cast<const uint8_t*>(nd)[q_off];  // issued ahead of the header's wait
+            u32x8 hdr;
+            asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hdr) : "s"(nd) : "memory");
+            const float px_ = __uint_as_float(hdr[0]), py_ = __uint_as_float(hdr[1]), pz_ = __uint_as_float(hdr[2]);
+            const uint32_t w3 = hdr[3], child_base = hdr[4], tri_base = hdr[5], leafmask = hdr[6] & 0xffu;
+            const uint32_t imask = w3 >> 24;
+            // this lane's plane: p[axis] + q * 2^e[axis]; the axis is picked with 0 / 1 weights (three fast multiply-adds, one scalar
+            // operand each) instead of selects (the constant bus takes one scalar register per instruction)
+            const float ps = __uint_as_float((w3 << s_sh) & 0x7f800000u);
+            const float pp = __builtin_fmaf(w_z, pz_, __builtin_fmaf(w_y, py_, w_x * px_));
+            const float plane = __builtin_fmaf((float)q, ps, pp);
+            if (!PURE) {
+                __builtin_amdgcn_wave_barrier();  // the previous node's plane reads are done (one wave: DS ops run in order)
+                planes[lane] = plane;             // child c: [near x y z, -, far x y z, -]
+                __builtin_amdgcn_wave_barrier();
+            }
+            // (1) interval test: lane 8c + k bounds its plane, quad maxima, near + (-far) <= 0 in lanes 8c..8c+3
+            const float u = plane - o_ax;
+            const float lo = fmin_(u * ia_a, u * ia_b);
+            float qm = __builtin_fmaf(__builtin_fabsf(lo), -0x1p-21f, lo - ia_m);
+            RT_DPP_MAX(qm, "quad_perm:[1,0,3,2]");
+            RT_DPP_MAX(qm, "quad_perm:[2,3,0,1]");  // every lane holds its quad's maximum
+            float gap;  // max(lower bounds of t_near, 0) - min(upper bounds of t_far, cap): all finite
+            asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(gap) : "v"(qm));
+            const float gap_c = __int_as_float(__builtin_amdgcn_ds_bpermute((int)v_addr, __float_as_int(gap)));
+            const uint32_t masks = imask | ((PURE ? leafmask : imask | leafmask) << 8);  // bits 8..15: what step (2) / the triangle loop may be handed
+            // (two ballots and a scalar AND: the AND of two i1 would go through v_cndmask and a third compare)
+            const uint32_t verdict = (uint32_t)__builtin_amdgcn_ballot_w64(gap_c <= 0.0f) & (uint32_t)__builtin_amdgcn_ballot_w64((int)(masks << v_sh) < 0);
+            uint32_t any;  // bit c: leaf / inner child slot c is entered (slot order)
+            uint32_t inner_hits;
+            if (PURE) {
+                any = verdict >> 8;
+                inner_hits = verdict << 24;
+            } else {  // (2) the rays' own slab tests of the children that passed
+                any = 0;
+                for (uint32_t m = (verdict >> 8) & 0xffu; m; m &= m - 1u) {
+                    const uint32_t c = (uint32_t)__builtin_ctz(m);
+                    const f4v a = planes4[2u * c], b = planes4[2u * c + 1u];
+                    const float tn = fmax_(fmax_(__builtin_fmaf(a.x, inv.x, noi.x), __builtin_fmaf(a.y, inv.y, noi.y)), fmax_(__builtin_fmaf(a.z, inv.z, noi.z), 0.0f));
+                    const float tf = fmin_(fmin_(__builtin_fmaf(b.x, inv.x, noi.x), __builtin_fmaf(b.y, inv.y, noi.y)), fmin_(__builtin_fmaf(b.z, inv.z, noi.z), best.t));
+                    // (scalar text: a uniform i1 is kept as a lane mask and comes back through v_cndmask + v_readfirstlane)
+                    const unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(tn <= tf) & act_mask;
+                    uint32_t some;
+                    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(some) : "s"(hit_mask) : "scc");
+                    any |= some << c;
+                }
+                // front-to-back order of the inner hits: lane p < 8 looks at bit p ^ oct, the ballot is the permuted byte
+                inner_hits = (uint32_t)__builtin_amdgcn_ballot_w64((int)((any & imask) << p_sh) < 0 && lane < 8u) << 24;
+            }
+            const float t_before = best.t;
+            for (uint32_t lh = any & leafmask; lh; lh &= lh - 1u) {  // the single triangles of the leaf slots that are entered
+                const uint32_t c = (uint32_t)__builtin_ctz(lh);
+                const uint32_t li = tri_base + (uint32_t)__builtin_popcount(leafmask & ((1u << c) - 1u));
+                const float* __restrict__ tp = reinterpret_cast<const float*>(sc.tris) + (size_t)li * 12u;  // wave-uniform address
+                if (COUNT) n_tris++;
+                float t;
+                if (act && tri_test(o, d, mk(tp[0], tp[1], tp[2]), mk(tp[3], tp[4], tp[5]), mk(tp[6], tp[7], tp[8]), t) && t > 0.0f) {
+                    const uint32_t id = __float_as_uint(tp[9]);
+                    if (t < best.t || (t == best.t && id < best.id)) {
+                        best.t = t;
+                        best.li = (int)li;
+                        best.id = id;
+                    }
+                }
+            }
+            if (FARCAP && (any & leafmask) != 0u && __builtin_amdgcn_ballot_w64(best.t < t_before) != 0ull) {  // wave-uniform
+                const float maxbest = wave_max_nonneg(act ? best.t : 0.0f);
+                if (pk == 7u) ia_m = maxbest;
+            }
+            gx = child_base;
+            gy = inner_hits | imask;
+            if (gy <= 0x00ffffffu) {  // no child entered: on with the newest pending group
+                sp--;
+                gx = (uint32_t)__builtin_amdgcn_readlane(stx, (int)sp);
+                gy = (uint32_t)__builtin_amdgcn_readlane(sty, (int)sp);
+            }
+        } while (gy != 0u);
+        if (sp_max > 63u) overflow = 1;
+    }
+    if (alive) st.hit[pid] = make_float2(best.t, __int_as_float(best.li));
+    if (COUNT && lane == 0) {  // records fetched once per wave
+        atomicAdd(&stats[9], (unsigned long long)n_nodes);
+        atomicAdd(&stats[10], (unsigned long long)n_tris);
+        atomicAdd(&stats[8], 1ull);
+    }
+    if (overflow && lane == 0) atomicOr((unsigned int*)&stats[2], 1u);
+}
+
 // ---- shade ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, const PtFrame f, PtState st, const uint32_t* __restrict__ queue,
                                                            const uint32_t* __restrict__ count_ptr, uint32_t depth, uint32_t* __restrict__ next_queue,
@@ -1614,10 +1827,23 @@ int launch_pt_trace_fused(Ctx* c, const PtScene& sc, const PtState& st, const ui
 
 uint32_t pt_pool_lds_bytes(uint32_t tri_mode) { return tri_mode == TRI_POOL ? kPoolLdsBytes : tri_mode == TRI_INLINE_PF ? kPfLdsBytes : 0u; }
 
-int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count) {
+int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count, uint32_t mode) {
     const dim3 g((f.n_paths + 255u) / 256u), b(256);
-    if (count) hipLaunchKernelGGL(pt_trace_packet<true>, g, b, 0, c->stream, sc, f, st, stats);
-    else hipLaunchKernelGGL(pt_trace_packet<false>, g, b, 0, c->stream, sc, f, st, stats);
+#define RT_LAUNCH_PACKET(K) hipLaunchKernelGGL(K, g, b, 0, c->stream, sc, f, st, stats)
+    if (mode == PACKET_EXACT) {
+        if (count) RT_LAUNCH_PACKET(pt_trace_packet<true>);
+        else RT_LAUNCH_PACKET(pt_trace_packet<false>);
+    } else if (mode == PACKET_INTERVAL_ONLY) {
+        if (count) RT_LAUNCH_PACKET((pt_trace_packet_ia<true, true, true>));
+        else RT_LAUNCH_PACKET((pt_trace_packet_ia<false, true, true>));
+    } else if (mode == PACKET_INTERVAL_NOCAP) {
+        if (count) RT_LAUNCH_PACKET((pt_trace_packet_ia<true, false, false>));
+        else RT_LAUNCH_PACKET((pt_trace_packet_ia<false, false, false>));
+    } else {
+        if (count) RT_LAUNCH_PACKET((pt_trace_packet_ia<true, false, true>));
+        else RT_LAUNCH_PACKET((pt_trace_packet_ia<false, false, true>));
+    }
+#undef RT_LAUNCH_PACKET
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }

@@ -22,6 +22,7 @@ namespace {
 constexpr uint64_t kMaxPathsInFlight = 1ull << 25;  // 33.5 M paths = 4.3 GB of wavefront state
 constexpr uint32_t kMaxBounces = 15;
 constexpr size_t kStatWords = 16;  // device-side traversal statistics (path_b.hip)
+constexpr uint32_t kDefaultPacketMode = rt::PACKET_INTERVAL;
 constexpr uint32_t kDefaultTriMode = rt::TRI_MODE_INLINE;  // rt_pt_params.tune_tri_mode = 0
 constexpr float kCameraReach = 32.0f;  // camera |coordinate| limit in units of the mesh's largest |coordinate| (render_pt_common)
 
@@ -274,7 +275,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
         RT_HIP(c, hipMemsetAsync(pt.d_ctr, 0, ctr_words * sizeof(uint32_t), c->stream));
         // camera rays through the packet kernel, which makes its own rays: no generate stage, no queue 0.  Its wave-uniform stack is a
         // fixed LDS array: a tree that may need more (a deep two-level tree) takes the per-lane kernel, whose stack is sized from stack_need
-        const bool packet = !prm->tune_no_packet && pt.stack_need <= rt::kPacketStackEntries;
+        const bool packet = prm->tune_no_packet != rt::PACKET_OFF && pt.stack_need <= rt::kPacketStackEntries;
         if (!packet) {
             rt::RoctxRange rr("rt.path_b.generate");
             tm.begin(0);
@@ -291,7 +292,7 @@ int render_pt_common(Ctx* c, const float rot[4], const float pos[3], const rt_pt
             rt::RoctxRange rr(d == 0 && packet ? "rt.path_b.trace_packet depth" : shadow_deferred ? "rt.path_b.trace_fused depth" : "rt.path_b.trace_closest depth", d);
             tm.begin(d == 0 && packet ? 5 : shadow_deferred ? 6 : 1);
             if (d == 0 && packet) {  // camera rays: one shared origin, coherent 4x4-pixel blocks per wave
-                if (int rc = rt::launch_pt_trace_packet(c, sc, f, pt.st, pt.d_stats, count)) return rc;
+                if (int rc = rt::launch_pt_trace_packet(c, sc, f, pt.st, pt.d_stats, count, prm->tune_no_packet == rt::PACKET_DEFAULT ? kDefaultPacketMode : prm->tune_no_packet)) return rc;
             } else if (shadow_deferred) {  // closest(d) + shadow(d - 1): ctr_d holds both the closest count of depth d and the shadow count of depth d - 1
                 if (int rc = rt::launch_pt_trace_fused(c, sc, pt.st, q, ctr_d + rt::PT_CTR_COUNT, ctr_d + rt::PT_CTR_HEAD_CLOSEST, ctr_d + rt::PT_CTR_SHADOW_COUNT,
                                                        ctr_d + rt::PT_CTR_HEAD_SHADOW, pt.d_stats, count, grid_persistent, stack_cap, refill_min, tri_mode, tri_cfg))

@@ -143,6 +143,9 @@ struct PtScene {
 };
 
 constexpr uint32_t kPacketStackEntries = 40;  // pt_trace_packet's LDS stack of node groups (path_b.hip)
+// rt_pt_params.tune_no_packet: 0 = default, 1 = no packet kernel (camera rays through the per-lane kernel), then the packet kernel's node test:
+// per-ray slab tests of all eight children; interval test for the pass, per-ray tests of the children that pass; interval test only; the second without the best-hit cap
+enum { PACKET_DEFAULT = 0, PACKET_OFF = 1, PACKET_EXACT = 2, PACKET_INTERVAL = 3, PACKET_INTERVAL_ONLY = 4, PACKET_INTERVAL_NOCAP = 5 };
 enum { TRI_MODE_INLINE = 1, TRI_MODE_POOL = 2, TRI_MODE_DEFER = 3, TRI_MODE_INLINE_PF = 4 };  // rt_pt_params.tune_tri_mode, byte 0 (path_b.hip: TRI_INLINE, TRI_POOL)
 
 struct StackCfg {  // per-lane traversal stack of 8-byte entries: lds_cap in LDS, then spill_cap in global memory
@@ -286,7 +289,7 @@ int launch_pt_trace_fused(Ctx* c, const PtScene& sc, const PtState& st, const ui
                           const uint32_t* shadow_count, uint32_t* shadow_head, unsigned long long* stats, bool count, uint32_t grid,
                           const StackCfg& stack_cap, uint32_t refill_min, uint32_t tri_mode, uint32_t tri_cfg);
 uint32_t pt_pool_lds_bytes(uint32_t tri_mode);  // static LDS a 256-thread workgroup of the per-lane kernels needs beyond the stacks and the octant table
-int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count);
+int launch_pt_trace_packet(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, unsigned long long* stats, bool count, uint32_t mode);
 int launch_pt_shade(Ctx* c, const PtScene& sc, const PtFrame& f, const PtState& st, const uint32_t* queue, const uint32_t* count_ptr,
                     uint32_t depth, uint32_t* next_queue, uint32_t* next_ctr, uint32_t grid, uint32_t sort_rays);
 int launch_pt_resolve(Ctx* c, const PtFrame& f, const PtState& st, float* acc, float* dst, int tile_major);

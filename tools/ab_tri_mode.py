@@ -78,4 +78,4 @@ for kw in variants:
           + f" | closest nodes/ray {c['nodes_visited'] / cr:.1f} tris/ray {c['tris_tested'] / cr:.2f}; shadow nodes/ray {c['shadow_nodes_visited'] / max(c['shadow_rays'], 1):.1f}"
           f" tris/ray {c['shadow_tris_tested'] / max(c['shadow_rays'], 1):.2f}; rounds {c['wave_rounds']} alive/round {c['alive_lane_rounds'] / max(c['wave_rounds'], 1):.1f}"
           f" all rounds {c['wave_rounds_all']} flushes {c['pool_flushes']} tris/flush {(c['tris_tested'] + c['shadow_tris_tested']) / max(c['pool_flushes'], 1):.1f}"
-          f" rays b {c['bounce_rays']} s {c['shadow_rays']}", flush=True)
+          f" rays b {c['bounce_rays']} s {c['shadow_rays']}; packet nodes/wave {c['packet_nodes_fetched'] / max(c['packets'], 1):.1f} tris/wave {c['packet_tris_fetched'] / max(c['packets'], 1):.1f}", flush=True)
