@@ -1387,13 +1387,17 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
     const uint32_t m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
     return __uint_as_float(m01 > m23 ? m01 : m23);
 }
-__device__ __forceinline__ float wave_min_f(float v) {
-    for (int off = 32; off > 0; off >>= 1) v = fmin_(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f(float v) {
-    for (int off = 32; off > 0; off >>= 1) v = fmax_(v, __shfl_xor(v, off));
-    return v;
+#define RT_DPP_MIN(v, ctrl) asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ float wave_min_nonneg(float v) {
+    RT_DPP_MIN(v, "quad_perm:[1,0,3,2]");
+    RT_DPP_MIN(v, "quad_perm:[2,3,0,1]");
+    RT_DPP_MIN(v, "row_half_mirror");
+    RT_DPP_MIN(v, "row_mirror");
+    const uint32_t b = __float_as_uint(v);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)b, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)b, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)b, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)b, 48);
+    const uint32_t m01 = r0 < r1 ? r0 : r1, m23 = r2 < r3 ? r2 : r3;
+    return __uint_as_float(m01 < m23 ? m01 : m23);
 }
 // bit 0 of each of the 8 bytes of m -> bits 0..7 (multiply-gather: the partial products land on distinct bits)
 __device__ __forceinline__ uint32_t gather_byte_lsbs(unsigned long long m) {
@@ -1440,10 +1444,14 @@ __global__ __launch_bounds__(256) void pt_trace_packet_ia(const PtScene sc, cons
         remaining &= ~act_mask;
         // the pass's range of 1 / d per axis (one sign per axis: the octant is shared), and this lane's share of it
         const float inf = __builtin_inff();
-        const float ix0 = wave_min_f(act ? inv.x : inf), ix1 = wave_max_f(act ? inv.x : -inf);
-        const float iy0 = wave_min_f(act ? inv.y : inf), iy1 = wave_max_f(act ? inv.y : -inf);
-        const float iz0 = wave_min_f(act ? inv.z : inf), iz1 = wave_max_f(act ? inv.z : -inf);
-        const float imin = p_axis == 0u ? ix0 : p_axis == 1u ? iy0 : iz0, imax = p_axis == 0u ? ix1 : p_axis == 1u ? iy1 : iz1;
+        // (by magnitude - rows by DPP, the four rows on the scalar unit in integer order - and the pass's sign put back; which end is
+        // "min" does not matter: the bounds below take the smaller of the two products)
+        const float ax = __builtin_fabsf(inv.x), ay = __builtin_fabsf(inv.y), az = __builtin_fabsf(inv.z);
+        const float ix0 = wave_min_nonneg(act ? ax : inf), ix1 = wave_max_nonneg(act ? ax : 0.0f);
+        const float iy0 = wave_min_nonneg(act ? ay : inf), iy1 = wave_max_nonneg(act ? ay : 0.0f);
+        const float iz0 = wave_min_nonneg(act ? az : inf), iz1 = wave_max_nonneg(act ? az : 0.0f);
+        const float i_sign = ((oct >> (2u - (p_axis < 2u ? p_axis : 2u))) & 1u) != 0u ? 1.0f : -1.0f;  // oct bit set: direction >= 0
+        const float imin = i_sign * (p_axis == 0u ? ix0 : p_axis == 1u ? iy0 : iz0), imax = i_sign * (p_axis == 0u ? ix1 : p_axis == 1u ? iy1 : iz1);
         // near lanes bound t from below: min(u * imin, u * imax); far lanes bound -t from below: min(u * -imin, u * -imax)
         const float ia_a = p_plane ? (p_far ? -imin : imin) : 0.0f, ia_b = p_plane ? (p_far ? -imax : imax) : 0.0f;
         // widening: a lane computes fma(plane, inv, -(o * inv)), off the exact (plane - o) * inv by at most 2^-24 (|o * inv| + |t|)
@@ -1465,7 +1473,8 @@ __global__ __launch_bounds__(256) void pt_trace_packet_ia(const PtScene sc, cons
         int stx = 0, sty = 0;                // entry 0 = (0, 0): the end marker
         uint32_t sp = 1, sp_max = 0;
         uint32_t gx = 0u, gy = 0x80000000u;  // the root group
-        do {  // (gx, gy) holds at least one child
+        for (;;) {
+        do {  // (gx, gy) holds at least one child; the inner loop descends while some child is entered
             const uint32_t lz = (uint32_t)__builtin_clz(gy);  // 0..7: the front-most pending child is bit 31 - lz
             const uint32_t hits = gy;
             gy &= ~(0x80000000u >> lz);
@@ -1529,34 +1538,51 @@ __global__ __launch_bounds__(256) void pt_trace_packet_ia(const PtScene sc, cons
                 // front-to-back order of the inner hits: lane p < 8 looks at bit p ^ oct, the ballot is the permuted byte
                 inner_hits = (uint32_t)__builtin_amdgcn_ballot_w64((int)((any & imask) << p_sh) < 0 && lane < 8u) << 24;
             }
-            const float t_before = best.t;
+            unsigned long long improved = 0ull;  // wave-uniform: lanes whose best hit moved at this node
             for (uint32_t lh = any & leafmask; lh; lh &= lh - 1u) {  // the single triangles of the leaf slots that are entered
                 const uint32_t c = (uint32_t)__builtin_ctz(lh);
                 const uint32_t li = tri_base + (uint32_t)__builtin_popcount(leafmask & ((1u << c) - 1u));
                 const float* __restrict__ tp = reinterpret_cast<const float*>(sc.tris) + (size_t)li * 12u;  // wave-uniform address
                 if (COUNT) n_tris++;
-                float t;
-                if (act && tri_test(o, d, mk(tp[0], tp[1], tp[2]), mk(tp[3], tp[4], tp[5]), mk(tp[6], tp[7], tp[8]), t) && t > 0.0f) {
-                    const uint32_t id = __float_as_uint(tp[9]);
-                    if (t < best.t || (t == best.t && id < best.id)) {
-                        best.t = t;
-                        best.li = (int)li;
-                        best.id = id;
-                    }
-                }
+                // tri_test() with the same operations in the same order, but as straight-line code with lane masks and ONE wave-uniform
+                // way out: its per-lane early returns cost about sixty scalar instructions per triangle in exec-mask bookkeeping
+                const v3 v0 = mk(tp[0], tp[1], tp[2]), e1 = mk(tp[3], tp[4], tp[5]), e2 = mk(tp[6], tp[7], tp[8]);
+                const v3 pvec = cross(d, e2);
+                const float det = dot(e1, pvec);
+                const v3 tvec = o - v0;
+                const float u = dot(tvec, pvec);
+                const v3 qvec = cross(tvec, e1);
+                const float v = dot(d, qvec);
+                const float uv = u + v;
+                // (ballots, combined as 64-bit scalars: boolean expressions come back as branches or through v_cndmask + v_cmp)
+                const unsigned long long m_pos = __builtin_amdgcn_ballot_w64(det > 0.0f), m_nz = __builtin_amdgcn_ballot_w64(det != 0.0f);
+                const unsigned long long out_pos = __builtin_amdgcn_ballot_w64(u < 0.0f) | __builtin_amdgcn_ballot_w64(v < 0.0f) | __builtin_amdgcn_ballot_w64(uv > det);
+                const unsigned long long out_neg = __builtin_amdgcn_ballot_w64(u > 0.0f) | __builtin_amdgcn_ballot_w64(v > 0.0f) | __builtin_amdgcn_ballot_w64(uv < det);
+                const unsigned long long inside = act_mask & m_nz & ((m_pos & ~out_pos) | (~m_pos & ~out_neg));
+                if (inside == 0ull) continue;
+                const float t = dot(e2, qvec) / det;
+                const uint32_t id = __float_as_uint(tp[9]);
+                const unsigned long long closer = __builtin_amdgcn_ballot_w64(t < best.t) | (__builtin_amdgcn_ballot_w64(t == best.t) & __builtin_amdgcn_ballot_w64(id < best.id));
+                const unsigned long long take = inside & __builtin_amdgcn_ballot_w64(t > 0.0f) & closer;
+                if (FARCAP) improved |= take;
+                const bool mine = __builtin_amdgcn_inverse_ballot_w64(take);
+                best.t = mine ? t : best.t;
+                best.li = mine ? (int)li : best.li;
+                best.id = mine ? id : best.id;
             }
-            if (FARCAP && (any & leafmask) != 0u && __builtin_amdgcn_ballot_w64(best.t < t_before) != 0ull) {  // wave-uniform
+            if (FARCAP && improved != 0ull) {
                 const float maxbest = wave_max_nonneg(act ? best.t : 0.0f);
                 if (pk == 7u) ia_m = maxbest;
             }
             gx = child_base;
             gy = inner_hits | imask;
-            if (gy <= 0x00ffffffu) {  // no child entered: on with the newest pending group
-                sp--;
-                gx = (uint32_t)__builtin_amdgcn_readlane(stx, (int)sp);
-                gy = (uint32_t)__builtin_amdgcn_readlane(sty, (int)sp);
-            }
-        } while (gy != 0u);
+        } while (gy > 0x00ffffffu);
+            // no child entered: on with the newest pending group
+            sp--;
+            gx = (uint32_t)__builtin_amdgcn_readlane(stx, (int)sp);
+            gy = (uint32_t)__builtin_amdgcn_readlane(sty, (int)sp);
+            if (gy == 0u) break;
+        }
         if (sp_max > 63u) overflow = 1;
     }
     if (alive) st.hit[pid] = make_float2(best.t, __int_as_float(best.li));

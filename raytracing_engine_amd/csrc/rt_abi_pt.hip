@@ -22,7 +22,7 @@ namespace {
 constexpr uint64_t kMaxPathsInFlight = 1ull << 25;  // 33.5 M paths = 4.3 GB of wavefront state
 constexpr uint32_t kMaxBounces = 15;
 constexpr size_t kStatWords = 16;  // device-side traversal statistics (path_b.hip)
-constexpr uint32_t kDefaultPacketMode = rt::PACKET_INTERVAL;
+constexpr uint32_t kDefaultPacketMode = rt::PACKET_INTERVAL_ONLY;
 constexpr uint32_t kDefaultTriMode = rt::TRI_MODE_INLINE;  // rt_pt_params.tune_tri_mode = 0
 constexpr float kCameraReach = 32.0f;  // camera |coordinate| limit in units of the mesh's largest |coordinate| (render_pt_common)
 

@@ -247,10 +247,12 @@ def _knob_scene():
                                    dict(tune_tri_mode=3, tune_no_overlap=2, tune_refill_min=64),
                                    dict(tune_tri_mode=4), dict(tune_tri_mode=4, tune_refill_min=1), dict(tune_tri_mode=4, tune_refill_min=64), dict(tune_tri_mode=4, tune_refill_min=24 | (3 << 8)),
                                    dict(tune_tri_mode=4, tune_no_packet=1, tune_no_overlap=1, tune_lds_stack=1), dict(tune_tri_mode=4, tune_no_overlap=2, tune_blocks_per_cu=1),
-                                   dict(tune_tri_mode=4, tune_sort_rays=1), dict(tune_sort_rays=2), dict(tune_sort_rays=2, tune_no_packet=1, tune_refill_min=8)])
+                                   dict(tune_tri_mode=4, tune_sort_rays=1), dict(tune_sort_rays=2), dict(tune_sort_rays=2, tune_no_packet=1, tune_refill_min=8),
+                                   dict(tune_no_packet=2), dict(tune_no_packet=3), dict(tune_no_packet=4), dict(tune_no_packet=5), dict(tune_no_packet=3, tune_no_overlap=1)])
 def test_scheduling_knobs_do_not_change_the_frame(renderer, knobs):
     """Refill threshold, triangle tests per round, inline / wave-pooled triangle tests and the pool's flush rule, resident
-    workgroups, LDS / spill split of the traversal stack, rays sorted in LDS, launch overlap: pure scheduling, so the frame and
+    workgroups, LDS / spill split of the traversal stack, rays sorted in LDS, launch overlap, the packet kernel's node test
+    (per-ray slab tests / interval test per pass, with and without the per-ray second step): pure scheduling, so the frame and
     the ray counts must equal the ORACLE's (not just the default configuration's)."""
     k = _knob_scene()
     renderer.set_mesh(*k["mesh"])
@@ -452,16 +454,24 @@ def test_two_level_bvh_frames_counts_and_chunk_rebuild(renderer, walker, tmp_pat
 def test_packet_kernel_camera_poses(renderer, yaw, pitch, pos, spp, w, h):
     """The camera rays go through the wave-uniform packet kernel (one tree walk per 64 paths, lanes of a deviating direction
     octant in a further pass): frames and ray counts must be the oracle's for views whose packets mix octants, for sample
-    counts that do not tile a wave, for a camera inside the mesh, and must equal the per-lane kernel's (tune_no_packet)."""
+    counts that do not tile a wave, for a camera inside the mesh, and must equal the per-lane kernel's and every node-test
+    variant's of the packet kernel (tune_no_packet)."""
     mesh = scenes.soup_scene(20000, seed=17, edge=0.7)
     rot = R.camera_quat(yaw, pitch)
     rgb, ref, st = check_pt(renderer, mesh, w, h, rot=rot, pos=pos, spp=spp, bounces=1, seed=9, sky=(0.3, 0.3, 0.4))
     assert st["camera_rays"] == w * h * spp
-    per_lane = renderer.render_pt(rot, pos, spp=spp, bounces=1, seed=9, sky=(0.3, 0.3, 0.4), tune_no_packet=1)
-    assert np.array_equal(rgb, per_lane)
-    renderer.render_pt(rot, pos, spp=spp, bounces=1, seed=9, sky=(0.3, 0.3, 0.4), count_traversal=True)
-    ct = renderer.pt_stats()
-    assert ct["packets"] == -(-(-(-w // 64) * -(-h // 64) * 4096 * spp) // 64) and ct["packet_nodes_fetched"] >= ct["packets"]
+    for mode in (1, 2, 3, 4, 5):  # per-lane kernel; packet kernel with per-ray slab tests; interval test + slab tests; interval test only; ... without the cap
+        other = renderer.render_pt(rot, pos, spp=spp, bounces=1, seed=9, sky=(0.3, 0.3, 0.4), tune_no_packet=mode)
+        assert np.array_equal(rgb, other), mode
+    fetched = {}
+    for mode in (2, 3, 4):
+        renderer.render_pt(rot, pos, spp=spp, bounces=1, seed=9, sky=(0.3, 0.3, 0.4), count_traversal=True, tune_no_packet=mode)
+        ct = renderer.pt_stats()
+        assert ct["packets"] == -(-(-(-w // 64) * -(-h // 64) * 4096 * spp) // 64) and ct["packet_nodes_fetched"] >= ct["packets"]
+        assert ct["stack_overflow"] == 0
+        fetched[mode] = (ct["packet_nodes_fetched"], ct["packet_tris_fetched"])
+    # the interval test lets through a superset of the children some ray hits, and with the per-ray second step exactly those
+    assert fetched[3] == fetched[2] and fetched[4][0] >= fetched[2][0] and fetched[4][1] >= fetched[2][1]
 
 
 def test_chunk_update_accepts_the_mesh_it_was_built_from(renderer):
