@@ -250,8 +250,12 @@ typedef struct rt_pt_params {
     uint32_t tune_no_overlap;    /* tuning: how the shadow rays of depth d and the closest-hit rays of depth d + 1 (independent work) share the
                                     GPU: 0 (default) one persistent launch pulls from both queues; 1 one launch after the other;
                                     2 two launches on two streams */
-    uint32_t tune_no_packet;     /* tuning: 1 = camera rays go through the per-lane traversal kernel like every other ray
-                                    (default 0: wave-uniform packet traversal for camera rays) */
+    uint32_t tune_no_packet;     /* tuning: how the camera rays are traced.  0 = default (4); 1 = through the per-lane traversal kernel
+                                    like every other ray; 2..5 = wave-uniform packet traversal (one tree walk per 64 camera rays)
+                                    with the node test as: 2 = every ray's slab test of all eight children; 3 = one interval test
+                                    per child for the whole wave, then the rays' slab tests of the children that pass; 4 = the
+                                    interval test alone; 5 = 3 without the cap at the wave's farthest best hit.
+                                    Frames do not depend on it. */
     uint32_t tune_sort_rays;     /* tuning: 1 = bounce and shadow rays are sorted inside each 1024-ray workgroup of the shade stage
                                     (LDS counting sort on direction octant + origin cell) before they enter the queues;
                                     2 = the same sort on keys that predict work (shadow rays: segment length in quarter-octaves;

@@ -17,6 +17,7 @@ import raytracing_engine_amd as R  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=6)
 ap.add_argument("--frames", type=int, default=24)
+ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--no-detile", action="store_true")
 ap.add_argument("--tune", default="", help="k=v,k=v tuning knobs of rt_pt_params")
 a = ap.parse_args()
@@ -49,12 +50,16 @@ def run(lanes, n_ranks):
         frame(i, lanes, n_ranks)
     for r in rs:
         r.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.frames):
-        frame(i, lanes, n_ranks)
-    for r in rs:
-        r.synchronize()
-    return (time.perf_counter() - t0) / a.frames * 1e3
+    best = None
+    for _ in range(a.reps):  # the best of a few repetitions: a single host-side stall of 20-30 ms inside one 24-frame window otherwise doubles a row's entry
+        t0 = time.perf_counter()
+        for i in range(a.frames):
+            frame(i, lanes, n_ranks)
+        for r in rs:
+            r.synchronize()
+        t = (time.perf_counter() - t0) / a.frames * 1e3
+        best = t if best is None else min(best, t)
+    return best
 
 
 base = run(1, 1)
