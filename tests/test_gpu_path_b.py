@@ -474,6 +474,36 @@ def test_packet_kernel_camera_poses(renderer, yaw, pitch, pos, spp, w, h):
     assert fetched[3] == fetched[2] and fetched[4][0] >= fetched[2][0] and fetched[4][1] >= fetched[2][1]
 
 
+def test_packet_kernel_random_views(renderer):
+    """The interval test of the packet kernel is a conservative filter: whatever the view, the frame must be the per-lane kernel's
+    bit for bit.  Forty random views of three meshes - a sparse soup, a dense one whose triangles are large against the packets,
+    the closed terrain - from outside, inside and far away, axis-parallel directions (a zero direction component makes one
+    axis of the interval unbounded) included, with sample counts and sizes that leave lanes of a wave without a ray."""
+    rng = np.random.default_rng(20251005)
+    meshes = [scenes.soup_scene(6000, seed=3, edge=0.5), scenes.soup_scene(1500, seed=4, edge=4.0), scenes.terrain_scene(48, seed=2)]
+    sizes = [(96, 64), (70, 40), (131, 33), (64, 64)]
+    for k in range(40):
+        mesh = meshes[k % 3]
+        w, h = sizes[k % 4]
+        renderer.set_mesh(*mesh)
+        renderer.resize(w, h)
+        if k % 8 == 7:  # axis-parallel view directions
+            yaw, pitch = float(rng.integers(0, 4)) * np.pi / 2, float(rng.integers(-1, 2)) * np.pi / 2
+        else:
+            yaw, pitch = float(rng.uniform(-np.pi, np.pi)), float(rng.uniform(-1.5, 1.5))
+        scale = (3.0, 12.0, 60.0)[k % 3]
+        pos = tuple(float(x) for x in (rng.uniform(-1, 1, 3) * scale + np.array([0.0, 15.0, 0.0]) * (k % 3 != 2)))
+        spp = int(rng.integers(1, 6))
+        rot = R.camera_quat(yaw, pitch)
+        kw = dict(spp=spp, bounces=1, seed=k, sky=(0.3, 0.3, 0.4))
+        ref = renderer.render_pt(rot, pos, tune_no_packet=1, **kw)
+        assert renderer.pt_stats()["stack_overflow"] == 0
+        for mode in (0, 3, 2):
+            got = renderer.render_pt(rot, pos, tune_no_packet=mode, **kw)
+            assert np.array_equal(got, ref), (k, mode, yaw, pitch, pos, spp)
+            assert renderer.pt_stats()["stack_overflow"] == 0
+
+
 def test_chunk_update_accepts_the_mesh_it_was_built_from(renderer):
     """rt_update_mesh_chunk checks the new vertices against the coordinate range the box padding was chosen for.  That range is
     stored at build time: reconstructing it as pad / 2e-5 loses an ulp for about 8 % of the ranges (100.0 among them) and then
