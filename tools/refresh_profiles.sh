@@ -45,8 +45,14 @@ export RT_BENCH_TUNE=tune_sort_rays=1
 pmc sort_rays
 unset RT_BENCH_TUNE
 cd $R
+# round 3: the packet kernel's node tests (per-ray slab tests of all eight children / interval test + per-ray tests of the children that pass;
+# the default - interval test only - is in pmc_summary_default.txt) and their A/B on both scenes
+bash tools/pmc_pass.sh pk_exact tune_no_packet=2
+bash tools/pmc_pass.sh pk_interval tune_no_packet=3
+python3 tools/ab_tri_mode.py --variants "tune_no_packet=2;tune_no_packet=3;tune_no_packet=4;tune_no_packet=5;tune_no_packet=1;tune_no_packet=2;tune_no_packet=4" > $O/ab_packet.txt 2>&1
+python3 tools/ab_tri_mode.py --scene terrain --variants "tune_no_packet=2;tune_no_packet=3;tune_no_packet=4;tune_no_packet=5;tune_no_packet=1;tune_no_packet=2;tune_no_packet=4" > $O/ab_packet_terrain.txt 2>&1
 python3 tools/ab_pt_variants.py > $O/ab_pt_variants.txt
-python3 tools/partition_scaling.py --lanes 3 > $O/partition_scaling.txt
+python3 tools/partition_scaling.py --lanes 6 > $O/partition_scaling.txt
 python3 tools/two_level_bvh.py > $O/two_level_bvh.txt
 python3 tools/run_configs.py --out $O/configs.json > $O/configs.md
 [ -x tools/_bin/valu ] && tools/_bin/valu > $O/valu_issue_rates.txt
