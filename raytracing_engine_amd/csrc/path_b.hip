@@ -87,6 +87,25 @@ __device__ __forceinline__ bool tri_test(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float&
     return true;
 }
 
+// tri_test() for the lanes of a wave that hold a triangle, as straight-line code: the same operations in the same order, the
+// per-lane early returns replaced by lane masks combined on the scalar unit and ONE wave-uniform way out before the division.
+__device__ __forceinline__ bool tri_test_flat(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float& t_out) {
+    const v3 pvec = cross(d, e2);
+    const float det = dot(e1, pvec);
+    const v3 tvec = o - v0;
+    const float u = dot(tvec, pvec);
+    const v3 qvec = cross(tvec, e1);
+    const float v = dot(d, qvec);
+    const float uv = u + v;
+    const unsigned long long m_pos = __builtin_amdgcn_ballot_w64(det > 0.0f), m_nz = __builtin_amdgcn_ballot_w64(det != 0.0f);
+    const unsigned long long out_pos = __builtin_amdgcn_ballot_w64(u < 0.0f) | __builtin_amdgcn_ballot_w64(v < 0.0f) | __builtin_amdgcn_ballot_w64(uv > det);
+    const unsigned long long out_neg = __builtin_amdgcn_ballot_w64(u > 0.0f) | __builtin_amdgcn_ballot_w64(v > 0.0f) | __builtin_amdgcn_ballot_w64(uv < det);
+    const unsigned long long inside = m_nz & ((m_pos & ~out_pos) | (~m_pos & ~out_neg));  // (ballots hold the active lanes only)
+    if (inside == 0ull) return false;
+    t_out = dot(e2, qvec) / det;
+    return __builtin_amdgcn_inverse_ballot_w64(inside);
+}
+
 __device__ __forceinline__ v3 safe_inv(v3 d) {
     const float x = __builtin_fabsf(d.x) > 1e-20f ? d.x : __builtin_copysignf(1e-20f, d.x);
     const float y = __builtin_fabsf(d.y) > 1e-20f ? d.y : __builtin_copysignf(1e-20f, d.y);
@@ -256,7 +275,7 @@ __device__ __forceinline__ bool tri_step(const float4* __restrict__ tris, TRay& 
     const float4 a = tp[0], b = tp[1], c = tp[2];
     if (COUNT) tc.tris++;
     float t;
-    if (tri_test(r.o, r.d, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t) && t > 0.0f) {
+    if (tri_test_flat(r.o, r.d, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t) && t > 0.0f) {
         if (ANY) return t < kShadowTmax;
         const uint32_t id = __float_as_uint(c.y);
         if (t < best.t || (t == best.t && id < best.id)) {
@@ -279,7 +298,7 @@ __device__ __forceinline__ bool tri_step_mixed(const float4* __restrict__ tris, 
     const float4 a = tp[0], b = tp[1], c = tp[2];
     if (COUNT) tc.tris++;
     float t;
-    if (tri_test(r.o, r.d, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t) && t > 0.0f) {
+    if (tri_test_flat(r.o, r.d, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), t) && t > 0.0f) {
         if (is_any) return t < kShadowTmax;
         const uint32_t id = __float_as_uint(c.y);
         if (t < best.t || (t == best.t && id < best.id)) {
