@@ -1386,10 +1386,6 @@ __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const P
 // enters every child that passes (1).  Both walk a superset of the boxes each ray would visit alone and test every
 // triangle with the ray's own arithmetic, so frames are unchanged.
 typedef __attribute__((address_space(3))) float lds_f32;
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
 // v = max(v, v of the lane the DPP control names); written out because the builtin form (v_mov_dpp, then fmaxf) pays a
 // canonicalising v_max per operand.  s_nop 1: a DPP read of a VGPR needs two wait states behind the VALU write, which the
 // compiler does not insert for text it does not parse.
@@ -1418,12 +1414,6 @@ __device__ __forceinline__ float wave_min_nonneg(float v) {
     const uint32_t m01 = r0 < r1 ? r0 : r1, m23 = r2 < r3 ? r2 : r3;
     return __uint_as_float(m01 < m23 ? m01 : m23);
 }
-// bit 0 of each of the 8 bytes of m -> bits 0..7 (multiply-gather: the partial products land on distinct bits)
-__device__ __forceinline__ uint32_t gather_byte_lsbs(unsigned long long m) {
-    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
-    return (((lo * 0x00204081u) >> 21) & 0xfu) | ((((hi * 0x00204081u) >> 21) & 0xfu) << 4);
-}
-
 template <bool COUNT, bool PURE, bool FARCAP>
 __global__ __launch_bounds__(256) void pt_trace_packet_ia(const PtScene sc, const PtFrame f, PtState st, unsigned long long* __restrict__ stats) {
     __shared__ f4v s_planes[4][16];
