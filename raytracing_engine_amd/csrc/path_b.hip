@@ -1380,11 +1380,13 @@ __global__ __launch_bounds__(256) void pt_trace_packet(const PtScene sc, const P
 // pass's lanes (per axis) every lane's slab distance (plane - o) * inv lies between the products with the two ends; lane
 // 8c + k holds plane k of child c (k = 0..2 near x y z, 4..6 far x y z, 3 / 7 the constants 0 and -(largest best.t)),
 // turns it into a LOWER bound of t_near resp. of -t_far (widened by the rounding of the lanes' own fma form), and two
-// quad-wide DPP maxima + one half-row mirror give  max(lower bounds of t_near, 0) <= min(upper bounds of t_far, best)  in
-// lane 8c: ten vector instructions for all eight children.  (2) Only children that pass - 1.2 of 8 on the metric's scene
-// are hit by any ray - get the per-ray slab test of the kernel above (planes parked in LDS as there); PURE skips (2) and
-// enters every child that passes (1).  Both walk a superset of the boxes each ray would visit alone and test every
-// triangle with the ray's own arithmetic, so frames are unchanged.
+// quad-wide DPP maxima + one half-row mirror add give  max(lower bounds of t_near, 0) - min(upper bounds of t_far, best)  in
+// lane 8c; one ds_bpermute hands the eight verdicts to lanes 0..15 in the two orders the bookkeeping wants (front to back for
+// the inner children, slot order for the leaves), so ONE ballot is the next node group and the leaf list: about ten vector
+// instructions for all eight children.  (2) Only children that pass - 1.2 of 8 on the metric's scene are hit by any ray -
+// get the per-ray slab test of the kernel above (planes parked in LDS as there); PURE skips (2) and enters every child that
+// passes (1).  Both walk a superset of the boxes each ray would visit alone and test every triangle with the ray's own
+// arithmetic, so frames are unchanged.  The traversal stack lives in two VGPRs (entry i in lane i).
 typedef __attribute__((address_space(3))) float lds_f32;
 // v = max(v, v of the lane the DPP control names); written out because the builtin form (v_mov_dpp, then fmaxf) pays a
 // canonicalising v_max per operand.  s_nop 1: a DPP read of a VGPR needs two wait states behind the VALU write, which the
