@@ -1606,7 +1606,7 @@ __global__ __launch_bounds__(256) void pt_trace_packet_ia(const PtScene sc, cons
 }
 
 // ---- shade ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kAppendThreads) void pt_shade(const PtScene sc, const PtFrame f, PtState st, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(kAppendThreads, 8) void pt_shade(const PtScene sc, const PtFrame f, PtState st, const uint32_t* __restrict__ queue,
                                                            const uint32_t* __restrict__ count_ptr, uint32_t depth, uint32_t* __restrict__ next_queue,
                                                            uint32_t* __restrict__ next_ctr, uint32_t sort_rays) {
     __shared__ uint32_t lds[kSortBins + 40];
