@@ -196,13 +196,13 @@ __device__ __forceinline__ float ubyte_f32(uint32_t w, int byte) {  // v_cvt_f32
 // Visit the nearest pending inner child of node group G: fetch its 80-byte record (five 16-byte
 // loads for eight children), slab-test the eight quantised boxes and turn the hits into a new node
 // group (inner children, ordered by ray octant) and a triangle group (leaf triangles).
-template <bool COUNT>
+template <bool COUNT, bool UNORDERED = false>
 __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, const uint8_t* perm_lut, const TRay& r, Group& G, Group& T, TravStack& stk, TravCounters& tc) {
     const uint32_t hits = G.y;
     const uint32_t bit = 31u - (uint32_t)__builtin_clz(hits);
     G.y &= ~(1u << bit);
     if (has_nodes(G)) stk.push(G, tc.overflow);  // remaining siblings
-    const uint32_t slot = (bit - 24u) ^ r.oct_inv;
+    const uint32_t slot = UNORDERED ? bit - 24u : (bit - 24u) ^ r.oct_inv;  // UNORDERED (any-hit rays of an all-shadow launch): children in slot order, no re-keying
     const uint32_t rel = (uint32_t)__builtin_popcount(hits & ~(0xffffffffu << slot));  // low byte of hits = imask
     const float4* nd = nodes + (size_t)(G.x + rel) * 5;
     const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3], n4 = nd[4];
@@ -246,7 +246,7 @@ __device__ __forceinline__ void node_step(const float4* __restrict__ nodes, cons
     // the hit bits are the work lists: inner children to enter, re-keyed front to back (bit slot -> bit slot ^ oct_inv,
     // one byte from a 2 KiB LDS table), and the leaf slots whose single triangle is to be tested
     const uint32_t leafmask = __float_as_uint(n1.z) & 0xffu;
-    const uint32_t keyed = perm_lut[r.oct_inv * 256u + (h8 & imask)];
+    const uint32_t keyed = UNORDERED ? (h8 & imask) : perm_lut[r.oct_inv * 256u + (h8 & imask)];
     G.x = __float_as_uint(n1.x);
     G.y = (keyed << 24) | imask;
     T.x = __float_as_uint(n1.y);
@@ -781,7 +781,7 @@ __device__ __forceinline__ void trace_queue(const PtScene& sc, const PtState& st
                     if (stk.sp) G = stk.pop();
                     else alive = false;
                 }
-                if (alive) node_step<COUNT>(sc.nodes, perm_lut, r, G, T, stk, tc);
+                if (alive) node_step<COUNT, ANY>(sc.nodes, perm_lut, r, G, T, stk, tc);
             }
             // triangle phase
 #pragma unroll 1
