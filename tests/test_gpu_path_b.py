@@ -110,6 +110,47 @@ def test_sample_passes_do_not_change_the_image(renderer):
     assert np.array_equal(one, ref)
 
 
+def test_rays_through_vertices_edges_and_duplicate_triangles(renderer):
+    """The boundary cases of the triangle test (u, v or u + v exactly on an edge; signed zeros) and the (t, id) tie-break: rays
+    straight through the vertices, edge midpoints and diagonals of a regular grid of quads, every triangle present TWICE (the
+    copy with the smaller original index must win a tie), from both sides (both signs of the determinant).  Closest hits and
+    occlusion must be the oracle's brute-force results bit for bit; the straight-line form of the test (tri_test_flat) is what runs."""
+    f = np.float32
+    tris = []
+    for i in range(-4, 4):
+        for j in range(-4, 4):
+            a_, b_, c_, d_ = (i, 5, j), (i + 1, 5, j), (i + 1, 5, j + 1), (i, 5, j + 1)
+            tris += [a_ + b_ + c_, a_ + c_ + d_]
+    v = np.array(tris + tris, f)  # coplanar duplicates: ties on t for every hit
+    a = np.full((len(v), 3), 0.5, f)
+    e = np.zeros((len(v), 3), f)
+    e[-1] = 1.0
+    renderer.set_mesh(v, a, e)
+    sc = O.TriScene(v, a, e)
+    xs = np.arange(-4.5, 4.75, 0.25, dtype=f)
+    gx, gz = np.meshgrid(xs, xs)
+    n = gx.size
+    for y0, dy in ((0.0, 1.0), (9.0, -1.0)):  # from below and from above
+        o = np.stack([gx.ravel(), np.full(n, y0, f), gz.ravel()], 1).astype(f)
+        d = np.tile(np.array([0.0, dy, 0.0], f), (n, 1))
+        d[::3, 0] = -0.0  # signed zeros in the direction
+        t, tri = renderer.trace_rays(o, d)
+        hits = 0
+        for k in range(n):
+            rt_, rtt = sc.closest_hit(o[k], d[k], use_bvh=False)
+            assert tri[k] == rt_, (k, o[k], tri[k], rt_)
+            if rt_ >= 0:
+                hits += 1
+                assert t[k] == np.float32(rtt) and rt_ < len(tris)  # the lower index of a duplicate pair
+        assert hits > n // 2
+        seg = (d * f(7.0)).astype(f)
+        _, occ = renderer.trace_rays(o, seg, any_hit=True)
+        ref = np.array([sc.occluded(o[k], seg[k], use_bvh=False) for k in range(n)])
+        assert np.array_equal(occ.astype(bool), ref)
+    # and through the render kernels (packet kernel for the camera rays): a camera below the grid, looking straight up
+    check_pt(renderer, (v, a, e), 65, 65, pos=(0.0, 0.0, 0.0), spp=2, bounces=1, sky=(0.4, 0.5, 0.6))
+
+
 def test_tiny_and_degenerate_meshes(renderer):
     f = np.float32
     one = (np.array([[-1, 5, -1, 1, 5, -1, 0, 5, 1]], f), np.array([[0.5, 0.6, 0.7]], f), np.zeros((1, 3), f))
