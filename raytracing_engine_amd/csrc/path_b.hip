@@ -1491,8 +1491,12 @@ __global__ __launch_bounds__(256) void pt_trace_packet_ia(const PtScene sc, cons
             gy &= ~(0x80000000u >> lz);
             if (gy > 0x00ffffffu) {  // remaining siblings
                 // (no builtin for v_writelane in this compiler; below gfx10 the lane select has to come through m0 when the value is a
-                // scalar register - one constant-bus operand.  m0 holds nothing of the compiler's here: gfx9 LDS access does not use it)
-                asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(stx), "+v"(sty) : "s"(gx), "s"(gy), "s"(sp));
+                // scalar register - one constant-bus operand.  m0 is a reserved register that cannot be named as a clobber, so the
+                // statement puts back what it found there)
+                uint32_t m0_saved;
+                asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
+                    : "+v"(stx), "+v"(sty), "=&s"(m0_saved)
+                    : "s"(gx), "s"(gy), "s"(sp));
                 sp++;
                 sp_max = sp_max > sp ? sp_max : sp;
             }
