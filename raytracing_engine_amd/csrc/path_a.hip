@@ -375,16 +375,33 @@ __device__ __forceinline__ bool shade_pixel(const ShadeSet S, const ShadeParams 
     return true;
 }
 
+// value of lane j of this lane's quad (v_mov_b32_dpp quad_perm:[j,j,j,j])
+__device__ __forceinline__ float quad_bcast(float v, int j) {
+    const int x = __float_as_int(v);
+    switch (j) {
+        case 0: return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x00, 0xf, 0xf, true));
+        case 1: return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0x55, 0xf, 0xf, true));
+        case 2: return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0xaa, 0xf, 0xf, true));
+        default: return __int_as_float(__builtin_amdgcn_mov_dpp(x, 0xff, 0xf, 0xf, true));
+    }
+}
+
 // Grid: 16 workgroups per owned framebuffer tile; every wave shades one 8x8 block of the tile.
-template <int N, bool REP, bool REFL>
+// SP (sample-parallel, batches of a multiple of four samples): 64 workgroups per tile, a wave shades a 4x4 block with FOUR lanes
+// per pixel, one sample each per round of four; lane 0 of the quad then adds the four colours in sample order (the other lanes'
+// values through DPP quad broadcasts) - the same sum, bit for bit, from four times as many waves of a quarter the length: a frame's
+// last waves (the pixels with the longest shadow marches) hold the machine for a quarter of the time.
+template <int N, bool REP, bool REFL, bool SP = false>
 __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const ShadeParams p, const float* __restrict__ depth,
                                                     float* __restrict__ dst, uint64_t* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t k = blockIdx.x >> 4;                                  // owned-tile index
-    const uint32_t sub = ((blockIdx.x & 15u) << 2) + (threadIdx.x >> 6);  // 8x8 block inside the tile
+    const uint32_t k = SP ? blockIdx.x >> 6 : blockIdx.x >> 4;                                           // owned-tile index
+    const uint32_t sub = SP ? ((blockIdx.x & 63u) << 2) + (threadIdx.x >> 6) : ((blockIdx.x & 15u) << 2) + (threadIdx.x >> 6);  // 4x4 / 8x8 block inside the tile
     const uint32_t tile = p.part.rank + k * p.part.n_ranks;
     const uint32_t tile_y = tile / p.part.tiles_x, tile_x = tile - tile_y * p.part.tiles_x;
-    const uint32_t lx = ((sub & 7u) << 3) + (lane & 7u), ly = ((sub >> 3) << 3) + (lane >> 3);
+    const uint32_t pix = lane >> 2, smp = lane & 3u;  // SP: pixel of the 4x4 block, sample of the round
+    const uint32_t lx = SP ? ((sub & 15u) << 2) + (pix & 3u) : ((sub & 7u) << 3) + (lane & 7u);
+    const uint32_t ly = SP ? ((sub >> 4) << 2) + (pix >> 2) : ((sub >> 3) << 3) + (lane >> 3);
     const uint32_t px = tile_x * RT_TILE + lx, py = tile_y * RT_TILE + ly;
     const bool inside = px < p.width && py < p.height;
 
@@ -400,19 +417,24 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
         have_sum = true;
     }
     uint32_t n_hits = 0, n_points = 0, n_refl = 0, n_trans = 0;
-    for (uint32_t sb = 0; sb < p.n_batch; sb++) {
-        float jx, jy, sr, sg, sbl;
+    for (uint32_t sb0 = 0; sb0 < p.n_batch; sb0 += SP ? 4u : 1u) {
+        const uint32_t sb = SP ? sb0 + smp : sb0;
+        float jx, jy, sr = 0.0f, sg = 0.0f, sbl = 0.0f;
         sample_jitter(p.sample0 + sb, p.n_strata, p.width, p.height, &jx, &jy);
         const bool hit = inside && shade_pixel<N, REP, REFL>(S, p, jx, jy, px, py, depth[(size_t)sb * p.depth_stride + (size_t)py * p.depth_w + px], sr, sg, sbl, n_points, n_refl, n_trans);  // :135
-        if (have_sum) {
-            r += sr;
-            g += sg;
-            b += sbl;
-        } else {
-            r = sr;
-            g = sg;
-            b = sbl;
-            have_sum = true;
+#pragma unroll
+        for (int j = 0; j < (SP ? 4 : 1); j++) {  // the round's samples in index order (SP: sample j sits in lane j of the quad)
+            const float cr = SP ? quad_bcast(sr, j) : sr, cg = SP ? quad_bcast(sg, j) : sg, cb = SP ? quad_bcast(sbl, j) : sbl;
+            if (have_sum) {
+                r += cr;
+                g += cg;
+                b += cb;
+            } else {
+                r = cr;
+                g = cg;
+                b = cb;
+                have_sum = true;
+            }
         }
         n_hits += (uint32_t)__popcll(__ballot(hit));
     }
@@ -433,7 +455,7 @@ __global__ __launch_bounds__(256) void shade_kernel(const ShadeSet S, const Shad
         }
     }
 
-    if (inside) {
+    if (inside && (!SP || smp == 0u)) {
         if (p.mode & 2u) {
             r = r / p.spp;
             g = g / p.spp;
@@ -586,6 +608,7 @@ static void shade_launch_n(hipStream_t st, dim3 grid, const ShadeSet& S, const S
     // the reference as shipped (no reflections, no transmission, no repetition) first; the sketched variants behind it
     if (p.reflections == 0 && p.transmissions == 0) {
         if (rep) hipLaunchKernelGGL((shade_kernel<N, true, false>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
+        else if ((p.n_batch & 3u) == 0u) hipLaunchKernelGGL((shade_kernel<N, false, false, true>), dim3(grid.x * 4u), dim3(256), 0, st, S, p, depth, dst, counters);  // four lanes per pixel
         else hipLaunchKernelGGL((shade_kernel<N, false, false>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
     } else {
         if (rep) hipLaunchKernelGGL((shade_kernel<N, true, true>), grid, dim3(256), 0, st, S, p, depth, dst, counters);
